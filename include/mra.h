@@ -1,0 +1,142 @@
+/* mra.h -- C ABI of the MI355X (gfx950) cross-modal encode/fuse/score hot path of mrAudio.
+ *
+ * The reference (globc/mrAudio) is pure Python and has no FFI; the boundary this library stands
+ * behind is the duck-typed seam inside XInstructBLIP.generate()/forward():
+ *     ln(encoder(frame))                                   models/xinstructblip.py:265,274,822-828
+ *     cat(embeds)[indices]                                 models/xinstructblip.py:281-285
+ *     {modality}_Qformer.bert(input_ids, attention_mask=, query_embeds=,
+ *                             encoder_hidden_states=, encoder_attention_mask=)   :286-293
+ *     {modality}_llm_proj(last_hidden_state[:, :32, :])    models/xinstructblip.py:303
+ * plus the similarity scorer the north star adds in place of the LLM decode (no reference site).
+ * Each entry point below names the reference call it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer on the handle's GPU;
+ *   - the caller (PyTorch) owns every buffer, including the workspace; after create/load the
+ *     library never allocates device memory and never synchronises the stream;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *   - return 0 on success, a negative MRA_E* code otherwise; mra_last_error() gives the text;
+ *   - a handle is bound to the device that was current at create; calls on one handle are not
+ *     re-entrant, distinct handles are independent (one per rank / modality);
+ *   - tensors are dense row-major; matrices of nn.Linear are [out, in] as PyTorch stores them.
+ */
+#ifndef MRA_H_
+#define MRA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRA_OK 0
+#define MRA_EINVAL (-1)    /* bad argument / unsupported shape */
+#define MRA_ESTATE (-2)    /* weights missing, handle not finalised ... */
+#define MRA_EHIP (-3)      /* a HIP call failed */
+#define MRA_ENOMEM (-4)    /* workspace too small / allocation failed */
+#define MRA_ENAME (-5)     /* unknown weight name */
+
+/* element types */
+#define MRA_F32 0
+#define MRA_F16 1
+#define MRA_BF16 2
+
+typedef struct mra_qformer mra_qformer;
+
+/* Shape of one modality Q-Former; defaults = reference models/xinstructblip.py:614-627
+ * (bert-base-uncased + cross-attention every 2nd layer, 32 queries, vocab 30522 + [DEC]). */
+typedef struct mra_cfg {
+  int32_t hidden;      /* 768; multiple of 256, <= 1024 */
+  int32_t heads;       /* 12; hidden / heads must be 64 */
+  int32_t inter;       /* 3072 */
+  int32_t layers;      /* 12 */
+  int32_t cross_freq;  /* 2: layers i % cross_freq == 0 carry cross-attention */
+  int32_t enc_width;   /* 1408 (EVA ViT-g) / 768 (BEATs); multiple of 64 */
+  int32_t n_query;     /* 32 (fixed by the kernels) */
+  int32_t vocab;       /* 30523 */
+  int32_t max_pos;     /* 512 */
+  float ln_eps;        /* 1e-12 (BERT LayerNorm) */
+  float enc_ln_eps;    /* 1e-5  (modality LayerNorm, torch default) */
+  int32_t llm_hidden;  /* 4096, or 0 when no llm_proj is loaded */
+  int32_t op_dtype;    /* MRA_F16 (default, the reference's autocast dtype) or MRA_BF16: MFMA operand type */
+} mra_cfg;
+
+/* Fills *cfg with the reference defaults for the given encoder width. */
+void mra_cfg_default(mra_cfg* cfg, int32_t enc_width);
+
+const char* mra_last_error(void);
+const char* mra_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * replaces: XInstructBLIP.init_Qformer / init_ln / init_vicuna_projection
+ * (models/xinstructblip.py:614-655,678-735): construction + weight loading. */
+int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out);
+void mra_qformer_destroy(mra_qformer* h);
+
+/* Copies (and converts to the operand dtype) one parameter.  `name` uses the LAVIS checkpoint keys
+ * with the leading "{modality}_Qformer." stripped, as the reference's loader does
+ * (models/xinstructblip.py:647-652): "bert.embeddings.word_embeddings.weight",
+ * "bert.encoder.layer.3.attention.self.query.weight", "...crossattention.output.LayerNorm.bias",
+ * "...intermediate_query.dense.weight" ... plus "query_tokens" ({m}_query_tokens),
+ * "ln.weight"/"ln.bias" ({m}_ln.*), "llm_proj.weight"/"llm_proj.bias" ({m}_llm_proj.*).
+ * src is a device pointer of `dtype` with `ndim` dims `shape`.  Unknown name -> MRA_ENAME. */
+int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t dtype, const int64_t* shape,
+                     int32_t ndim, void* stream);
+/* Number of parameters still missing (0 = ready); names are written comma separated into buf. */
+int mra_qformer_missing(mra_qformer* h, char* buf, size_t buflen);
+
+/* ---- A2 + A3: modality LayerNorm fused with the sample-major reorder ---------------------------
+ * replaces: ln(encoder(frame)) and torch.cat(embeds)[indices]
+ * (models/xinstructblip.py:265,274,281-285,822-828).
+ * x [n_src_items, tokens, enc_width] of x_dtype; item_index [items] int64 (NULL = identity) gives,
+ * for every output item, the source item; out [items, tokens, enc_width] in the operand dtype. */
+int mra_modality_ln(mra_qformer* h, const void* x, int32_t x_dtype, const int64_t* item_index, int32_t items,
+                    int32_t tokens, void* out, void* stream);
+
+/* ---- A4: Q-Former forward -----------------------------------------------------------------------
+ * replaces: {modality}_Qformer.bert(input_ids.repeat(T,1), attention_mask=..., query_embeds=
+ * query_tokens.repeat(T,1,1), encoder_hidden_states=..., encoder_attention_mask=ones)
+ * (models/xinstructblip.py:286-293).  The learned query tokens are the loaded "query_tokens"
+ * (the reference tiles the same [1,32,H] parameter for every item); encoder_attention_mask is
+ * all ones in the reference and is not an input here.
+ *   input_ids      [items, L] int64
+ *   attention_mask [items, n_query + L] int64 (1 = attend) or NULL = all ones
+ *   enc            [items, kv, enc_width] operand dtype (output of mra_modality_ln)
+ *   out_query      [items, n_query, hidden] f32 = last_hidden_state[:, :32, :]        (required)
+ *   out_full       [items, n_query + L, hidden] f32 = last_hidden_state, or NULL
+ *   out_cls        [items, hidden] f32 = last_hidden_state[:, 32, :], or NULL (needs L >= 1)
+ * When neither out_full nor out_cls is given the last layer's text feed-forward is skipped
+ * (its result is never read by the reference either: only [:, :32] is sliced, :303). */
+size_t mra_qformer_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv);
+int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
+                        int32_t items, int32_t L, int32_t kv, float* out_query, float* out_full, float* out_cls,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- A5: LLM projection ---------------------------------------------------------------------------
+ * replaces: {modality}_llm_proj(last_hidden_state[:, :32, :]) (models/xinstructblip.py:303).
+ * z [rows, hidden] f32 -> out [rows, llm_hidden] of out_dtype (MRA_F32 or the operand dtype).
+ * workspace: rows * hidden operand elements. */
+int mra_llm_proj(mra_qformer* h, const float* z, int32_t rows, void* out, int32_t out_dtype, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ---- A6: scorer (build-defined; the reference has no scorer) ----------------------------------
+ * sim[n][q] = cos(z[n][q][:], t[n or 0][:]); logit[n] = max_q sim[n][q].  sim may be NULL. */
+int mra_cosine_score(const float* z, const float* t, int32_t t_rows, int32_t items, int32_t n_query, int32_t hidden,
+                     float* sim, float* logit, void* stream);
+/* out[i] = sum_m weights[m] * logits[m][i] (weights NULL = 1/nmod), fp32, left to right. */
+int mra_fuse_logits(const float* const* logits, const float* weights, int32_t nmod, int32_t n, float* out,
+                    void* stream);
+/* spans[v] = (start, end) inclusive clip indices grown around the first argmax of
+ * logits[v*clips .. (v+1)*clips) while the neighbour >= lo + alpha * (hi - lo). */
+int mra_span_from_logits(const float* logits, int32_t videos, int32_t clips, float alpha, int32_t* spans,
+                         void* stream);
+
+/* ---- introspection for the bench ------------------------------------------------------------------
+ * Algorithmic flop count of one mra_qformer_forward (2 flops per MAC; formula in DESIGN.md). */
+double mra_qformer_flops(mra_qformer* h, int32_t items, int32_t L, int32_t kv, int32_t with_last_text);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRA_H_ */

@@ -1,0 +1,104 @@
+// Host-visible launchers of the gfx950 kernels.  Everything takes raw device pointers and a
+// stream; nothing here allocates, synchronises or touches torch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mra {
+
+enum OpDtype { OP_F16 = 0, OP_BF16 = 1 };
+
+// GEMM epilogues (C index is [activation row m][weight row n])
+enum GemmEpi {
+  EPI_OP = 0,       // C(op dtype) = acc + bias
+  EPI_GELU_OP = 1,  // C(op dtype) = gelu_erf(acc + bias)
+  EPI_RES_F32 = 2,  // C(f32)      = acc + bias + R
+  EPI_F32 = 3,      // C(f32)      = acc + bias
+  EPI_KV = 4,       // C(op dtype) head-major K/V cache, see GemmProb::kv_*
+};
+
+// Logical activation row m of a "row view" lives at base + (m / rpi) * item_stride + (m % rpi) * ld
+// (elements).  This lets the 32 query rows or the L text rows of every [S, H] item be addressed in
+// place, without gathers.
+struct RowView {
+  long long item_stride;
+  int rpi;  // rows per item
+  int ld;   // row stride
+};
+
+// One problem of a (possibly grouped) launch: C[m][n] = sum_k A[m][k] * W[n][k] (+ epilogue).
+struct GemmProb {
+  const void* A;      // activations, op dtype, row view `a`
+  const void* W;      // weights [N][K] row-major (the reference's nn.Linear layout), op dtype
+  const float* bias;  // [N] or nullptr
+  void* C;            // row view `c`
+  const float* R;     // residual (EPI_RES_F32), row view `r`
+  RowView a, c, r;
+  int M, N, K;
+  // EPI_KV: weight row n = (cl * 2 + kv) * hidden + head * 64 + d ; activation row m = item * kv_tokens + tok
+  // destination element ((((cl * 2 + kv) * kv_items + item) * kv_heads + head) * kv_tokens + tok) * 64 + d
+  int kv_tokens, kv_items, kv_heads;
+  int tile_begin;  // filled by the launcher
+  int mtiles, ntiles;
+};
+
+struct GemmArgs {
+  GemmProb p[2];
+  int ngroups;
+  int total_tiles;
+};
+
+// Returns 0 on success, <0 on bad shapes.  All problems of one launch share dtype / epilogue.
+int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream);
+// which tile config launch_gemm would pick (for tests / DESIGN.md): 0 = 64x64, 1 = 128x128, 2 = 256x256
+int gemm_pick_config(const GemmProb* probs, int ngroups);
+void gemm_force_config(int cfg);  // -1 = automatic (default)
+
+// ---- attention ------------------------------------------------------------------------------
+struct AttnArgs {
+  const void* Q;  // [item][q row][head*64 + d], op dtype
+  const void* K;  // token rows of 64 elements
+  const void* V;
+  void* O;        // [item][q row][head*64 + d], op dtype
+  long long q_item_stride, o_item_stride;  // elements
+  int q_ld, o_ld;
+  long long k_item_stride, k_head_stride;  // elements; token row stride = k_ld
+  long long v_item_stride, v_head_stride;
+  int k_ld, v_ld;
+  const long long* mask;  // [item][mask_ld] int64 (1 = attend) or nullptr; additive (1-m) * -10000
+  int mask_ld;
+  int items, heads, q_rows, kv_len;
+  float scale;   // 1/sqrt(64)
+  // grid-level KV split (cross attention with long KV): partials in `part`, combined by a 2nd kernel
+  int nsplit;
+  float* part;   // [items*heads*qblocks][nsplit][32*64 + 64] f32
+};
+size_t attn_partial_bytes(int items, int heads, int q_rows, int nsplit);
+int attn_pick_split(int items, int heads, int q_rows, int kv_len);
+int launch_attention(const AttnArgs& a, int op_dtype, hipStream_t stream);
+
+// ---- normalisation / embeddings / conversions -----------------------------------------------
+// y = LN(x) over H (multiple of 256, <= 1024) with gain/bias; writes f32 and/or op-dtype copies.
+int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, float eps,
+                   float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream);
+// Modality LayerNorm (A2) fused with the item gather (A3): out item i <- LN(in item index[i]).
+// x dtype: 0 = f32, 1 = f16, 2 = bf16.
+int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, int items, int tokens, int E,
+                       const float* gain, const float* bias, float eps, void* out, int op_dtype, hipStream_t stream);
+// Embeddings (A4a): h[n, s] = LN(s < Q ? query[s] : word[ids[n, s-Q]] + pos[s-Q])
+int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query, const float* word,
+                    const float* pos, const float* gain, const float* bias, float eps, float* h32, void* h16,
+                    int op_dtype, hipStream_t stream);
+// dst(op dtype)[rows][cols] at row offset <- src (0 = f32, 1 = f16, 2 = bf16)
+int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype /*0 f32,1 f16,2 bf16*/, long long n,
+                   hipStream_t stream);
+int launch_copy_rows_f32(const float* src, RowView sv, float* dst, RowView dv, int rows, int H, hipStream_t stream);
+
+// ---- scorer -------------------------------------------------------------------------------------
+int launch_cosine_score(const float* z, const float* t, int t_rows, int items, int Q, int H, float eps, float* sim,
+                        float* logit, hipStream_t stream);
+int launch_fuse_logits(const float* const* logits, const float* weights, int nmod, int n, float* out,
+                       hipStream_t stream);
+int launch_span(const float* logits, int videos, int clips, float alpha, int* spans, hipStream_t stream);
+
+}  // namespace mra

@@ -1,0 +1,645 @@
+// C ABI (include/mra.h) and the host-side orchestration of the Q-Former forward.
+//
+// Mirrors, launch by launch, what the reference gets from LAVIS' BertModel when it calls
+// {modality}_Qformer.bert(...) at models/xinstructblip.py:286-293 (layer structure as stated by
+// the HF port, modeling_instructblip.py:591-709), re-planned for gfx950:
+//   * the K/V projections of all cross-attention layers read the same encoder features, so they
+//     run as ONE GEMM [items*kv, E] x [n_cross*2*H, E]^T whose epilogue scatters into a head-major
+//     K/V cache ([kv][64] contiguous per (layer, k|v, item, head)) -- the layout the attention
+//     kernel streams with full 128-byte rows;
+//   * query rows and text rows of the [items, 32+L, H] residual stream are addressed in place
+//     through row views (no slicing copies); the two feed-forwards run as one grouped launch;
+//   * residual stream, LayerNorm statistics and softmax are fp32; only MFMA operands are f16/bf16.
+// No allocation and no synchronisation after create/load; everything is enqueued on `stream`.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mra.h"
+#include "kernels.h"
+
+using namespace mra;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(MRA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Param {
+  void* ptr = nullptr;   // destination inside the arena
+  int dtype = MRA_F32;   // stored dtype
+  long long numel = 0;   // elements expected from the source tensor
+  bool loaded = false;
+};
+
+struct LayerW {
+  void *wqkv, *wo, *wcq, *wco, *wiq, *woq, *wit, *wot;
+  float *bqkv, *bo, *bcq, *bco, *biq, *boq, *bit, *bot;
+  float *ln1g, *ln1b, *lncg, *lncb, *lnqg, *lnqb, *lntg, *lntb;
+  int cross_index;  // -1 when the layer has no cross-attention
+};
+
+}  // namespace
+
+struct mra_qformer {
+  mra_cfg cfg;
+  int device = 0;
+  int ncross = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::map<std::string, Param> params;
+  std::vector<LayerW> layers;
+  // embeddings / extras
+  float *word = nullptr, *pos = nullptr, *embg = nullptr, *embb = nullptr, *query = nullptr;
+  float *encg = nullptr, *encb = nullptr;
+  void* wkv = nullptr;  // [ncross*2*H, E]
+  float* bkv = nullptr;
+  void* wllm = nullptr;
+  float* bllm = nullptr;
+  int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
+};
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count, size_t elem = sizeof(T)) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(count * elem);
+    return p;
+  }
+};
+
+// Lays the parameter arena out; with base == nullptr only measures.
+size_t layout_params(mra_qformer* h, char* base) {
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, I = c.inter, E = c.enc_width;
+  Carver cv(base);
+  auto reg = [&](const std::string& name, void* p, int dtype, long long numel) {
+    Param pr;
+    pr.ptr = p;
+    pr.dtype = dtype;
+    pr.numel = numel;
+    h->params[name] = pr;
+  };
+  const int opd = c.op_dtype;
+  h->params.clear();
+  h->layers.assign(c.layers, LayerW{});
+  h->word = cv.take<float>((size_t)c.vocab * H);
+  h->pos = cv.take<float>((size_t)c.max_pos * H);
+  h->embg = cv.take<float>(H);
+  h->embb = cv.take<float>(H);
+  h->query = cv.take<float>((size_t)c.n_query * H);
+  h->encg = cv.take<float>(E);
+  h->encb = cv.take<float>(E);
+  reg("bert.embeddings.word_embeddings.weight", h->word, MRA_F32, (long long)c.vocab * H);
+  reg("bert.embeddings.position_embeddings.weight", h->pos, MRA_F32, (long long)c.max_pos * H);
+  reg("bert.embeddings.LayerNorm.weight", h->embg, MRA_F32, H);
+  reg("bert.embeddings.LayerNorm.bias", h->embb, MRA_F32, H);
+  reg("query_tokens", h->query, MRA_F32, (long long)c.n_query * H);
+  reg("ln.weight", h->encg, MRA_F32, E);
+  reg("ln.bias", h->encb, MRA_F32, E);
+  h->ncross = 0;
+  for (int i = 0; i < c.layers; ++i)
+    if (i % c.cross_freq == 0) ++h->ncross;
+  h->wkv = cv.take<char>((size_t)h->ncross * 2 * H * E, 2);
+  h->bkv = cv.take<float>((size_t)h->ncross * 2 * H);
+  if (c.llm_hidden > 0) {
+    h->wllm = cv.take<char>((size_t)c.llm_hidden * H, 2);
+    h->bllm = cv.take<float>(c.llm_hidden);
+    reg("llm_proj.weight", h->wllm, opd, (long long)c.llm_hidden * H);
+    reg("llm_proj.bias", h->bllm, MRA_F32, c.llm_hidden);
+  }
+  int cl = 0;
+  for (int i = 0; i < c.layers; ++i) {
+    LayerW& L = h->layers[i];
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+    char* wqkv = cv.take<char>(3 * H * H, 2);
+    L.wqkv = wqkv;
+    L.bqkv = cv.take<float>(3 * H);
+    const char* names[3] = {"query", "key", "value"};
+    for (int j = 0; j < 3; ++j) {
+      reg(p + "attention.self." + names[j] + ".weight", wqkv ? wqkv + (size_t)j * H * H * 2 : nullptr, opd, H * H);
+      reg(p + "attention.self." + names[j] + ".bias", L.bqkv ? L.bqkv + j * H : nullptr, MRA_F32, H);
+    }
+    L.wo = cv.take<char>(H * H, 2);
+    L.bo = cv.take<float>(H);
+    L.ln1g = cv.take<float>(H);
+    L.ln1b = cv.take<float>(H);
+    reg(p + "attention.output.dense.weight", L.wo, opd, H * H);
+    reg(p + "attention.output.dense.bias", L.bo, MRA_F32, H);
+    reg(p + "attention.output.LayerNorm.weight", L.ln1g, MRA_F32, H);
+    reg(p + "attention.output.LayerNorm.bias", L.ln1b, MRA_F32, H);
+    L.cross_index = -1;
+    if (i % c.cross_freq == 0) {
+      L.cross_index = cl;
+      L.wcq = cv.take<char>(H * H, 2);
+      L.bcq = cv.take<float>(H);
+      L.wco = cv.take<char>(H * H, 2);
+      L.bco = cv.take<float>(H);
+      L.lncg = cv.take<float>(H);
+      L.lncb = cv.take<float>(H);
+      reg(p + "crossattention.self.query.weight", L.wcq, opd, H * H);
+      reg(p + "crossattention.self.query.bias", L.bcq, MRA_F32, H);
+      char* wkv = (char*)h->wkv;
+      reg(p + "crossattention.self.key.weight", wkv ? wkv + (size_t)(cl * 2 + 0) * H * E * 2 : nullptr, opd, H * E);
+      reg(p + "crossattention.self.key.bias", h->bkv ? h->bkv + (size_t)(cl * 2 + 0) * H : nullptr, MRA_F32, H);
+      reg(p + "crossattention.self.value.weight", wkv ? wkv + (size_t)(cl * 2 + 1) * H * E * 2 : nullptr, opd, H * E);
+      reg(p + "crossattention.self.value.bias", h->bkv ? h->bkv + (size_t)(cl * 2 + 1) * H : nullptr, MRA_F32, H);
+      reg(p + "crossattention.output.dense.weight", L.wco, opd, H * H);
+      reg(p + "crossattention.output.dense.bias", L.bco, MRA_F32, H);
+      reg(p + "crossattention.output.LayerNorm.weight", L.lncg, MRA_F32, H);
+      reg(p + "crossattention.output.LayerNorm.bias", L.lncb, MRA_F32, H);
+      ++cl;
+    }
+    L.wit = cv.take<char>(I * H, 2);
+    L.bit = cv.take<float>(I);
+    L.wot = cv.take<char>(H * I, 2);
+    L.bot = cv.take<float>(H);
+    L.lntg = cv.take<float>(H);
+    L.lntb = cv.take<float>(H);
+    L.wiq = cv.take<char>(I * H, 2);
+    L.biq = cv.take<float>(I);
+    L.woq = cv.take<char>(H * I, 2);
+    L.boq = cv.take<float>(H);
+    L.lnqg = cv.take<float>(H);
+    L.lnqb = cv.take<float>(H);
+    reg(p + "intermediate.dense.weight", L.wit, opd, I * H);
+    reg(p + "intermediate.dense.bias", L.bit, MRA_F32, I);
+    reg(p + "output.dense.weight", L.wot, opd, H * I);
+    reg(p + "output.dense.bias", L.bot, MRA_F32, H);
+    reg(p + "output.LayerNorm.weight", L.lntg, MRA_F32, H);
+    reg(p + "output.LayerNorm.bias", L.lntb, MRA_F32, H);
+    reg(p + "intermediate_query.dense.weight", L.wiq, opd, I * H);
+    reg(p + "intermediate_query.dense.bias", L.biq, MRA_F32, I);
+    reg(p + "output_query.dense.weight", L.woq, opd, H * I);
+    reg(p + "output_query.dense.bias", L.boq, MRA_F32, H);
+    reg(p + "output_query.LayerNorm.weight", L.lnqg, MRA_F32, H);
+    reg(p + "output_query.LayerNorm.bias", L.lnqb, MRA_F32, H);
+  }
+  return cv.off;
+}
+
+// Workspace of one forward; with base == nullptr only measures.
+struct Work {
+  float *hA32, *hB32, *pre32, *hC32, *part;
+  char *hA16, *hB16, *qkv16, *ctx16, *qc16, *hC16, *ffn16, *kv16;
+  int nsplit;
+  size_t bytes;
+};
+
+Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, I = c.inter, S = c.n_query + L, Q = c.n_query;
+  Carver cv(base);
+  Work w;
+  w.hA32 = cv.take<float>(N * S * H);
+  w.hB32 = cv.take<float>(N * S * H);
+  w.pre32 = cv.take<float>(N * S * H);
+  w.hC32 = cv.take<float>(N * Q * H);
+  w.hA16 = cv.take<char>(N * S * H, 2);
+  w.hB16 = cv.take<char>(N * S * H, 2);
+  w.qkv16 = cv.take<char>(N * S * 3 * H, 2);
+  w.ctx16 = cv.take<char>(N * S * H, 2);
+  w.qc16 = cv.take<char>(N * Q * H, 2);
+  w.hC16 = cv.take<char>(N * Q * H, 2);
+  w.ffn16 = cv.take<char>(N * S * I, 2);
+  w.kv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
+  w.nsplit = attn_pick_split(N, c.heads, (int)Q, Kv);
+  w.part = nullptr;  // grid-split attention partials live right behind `bytes` (set by the caller)
+  w.bytes = cv.off;
+  return w;
+}
+
+RowView plain(int rows, int ld) { return RowView{0, rows > 0 ? rows : 1, ld}; }
+RowView items_view(long long item_stride, int rpi, int ld) { return RowView{item_stride, rpi, ld}; }
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int chk(int rc, const char* what) {
+  if (rc == 0) return 0;
+  return fail(rc == -1 ? MRA_EINVAL : MRA_EHIP, std::string(what) + " failed (rc " + std::to_string(rc) + ")");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mra_last_error(void) { return g_err.c_str(); }
+const char* mra_version(void) { return "mraudio_amd 0.1 (gfx950)"; }
+
+void mra_cfg_default(mra_cfg* c, int32_t enc_width) {
+  c->hidden = 768;
+  c->heads = 12;
+  c->inter = 3072;
+  c->layers = 12;
+  c->cross_freq = 2;
+  c->enc_width = enc_width;
+  c->n_query = 32;
+  c->vocab = 30523;
+  c->max_pos = 512;
+  c->ln_eps = 1e-12f;
+  c->enc_ln_eps = 1e-5f;
+  c->llm_hidden = 4096;
+  c->op_dtype = MRA_F16;
+}
+
+int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
+  if (!cfg || !out) return fail(MRA_EINVAL, "null argument");
+  const mra_cfg& c = *cfg;
+  if (c.hidden <= 0 || c.hidden % 256 || c.hidden > 1024) return fail(MRA_EINVAL, "hidden must be a multiple of 256, <= 1024");
+  if (c.heads <= 0 || c.hidden != c.heads * 64) return fail(MRA_EINVAL, "head_dim must be 64");
+  if (c.n_query != 32) return fail(MRA_EINVAL, "n_query must be 32");
+  if (c.inter <= 0 || c.inter % 256) return fail(MRA_EINVAL, "inter must be a multiple of 256");
+  if (c.enc_width <= 0 || c.enc_width % 64) return fail(MRA_EINVAL, "enc_width must be a multiple of 64");
+  if (c.layers <= 0 || c.cross_freq <= 0 || c.vocab <= 0 || c.max_pos <= 0) return fail(MRA_EINVAL, "bad layer/vocab config");
+  if (c.llm_hidden < 0 || c.llm_hidden % 256) return fail(MRA_EINVAL, "llm_hidden must be 0 or a multiple of 256");
+  if (c.op_dtype != MRA_F16 && c.op_dtype != MRA_BF16) return fail(MRA_EINVAL, "op_dtype must be MRA_F16 or MRA_BF16");
+  mra_qformer* h = new mra_qformer();
+  h->cfg = c;
+  HIP_TRY(hipGetDevice(&h->device));
+  h->arena_bytes = layout_params(h, nullptr);
+  hipError_t e = hipMalloc((void**)&h->arena, h->arena_bytes);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(MRA_ENOMEM, std::string("hipMalloc of parameter arena: ") + hipGetErrorString(e));
+  }
+  layout_params(h, h->arena);
+  *out = h;
+  return MRA_OK;
+}
+
+void mra_qformer_destroy(mra_qformer* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+
+int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t dtype, const int64_t* shape,
+                     int32_t ndim, void* stream) {
+  if (!h || !name || !src || (ndim > 0 && !shape)) return fail(MRA_EINVAL, "null argument");
+  if (dtype < MRA_F32 || dtype > MRA_BF16) return fail(MRA_EINVAL, "bad dtype");
+  const std::string key(name);
+  if (key == "bert.embeddings.position_ids") return MRA_OK;  // LAVIS buffer, not a parameter
+  auto it = h->params.find(key);
+  if (it == h->params.end()) return fail(MRA_ENAME, "unknown parameter name: " + key);
+  long long numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= shape[i];
+  if (numel != it->second.numel)
+    return fail(MRA_EINVAL, "parameter " + key + ": expected " + std::to_string(it->second.numel) + " elements, got " +
+                                std::to_string(numel));
+  const int rc = launch_convert(src, dtype, it->second.ptr, it->second.dtype, numel, as_stream(stream));
+  if (rc) return chk(rc, "launch_convert");
+  it->second.loaded = true;
+  return MRA_OK;
+}
+
+int mra_qformer_missing(mra_qformer* h, char* buf, size_t buflen) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  int n = 0;
+  std::string s;
+  for (auto& kv : h->params)
+    if (!kv.second.loaded) {
+      ++n;
+      if (!s.empty()) s += ",";
+      s += kv.first;
+    }
+  if (buf && buflen) {
+    std::strncpy(buf, s.c_str(), buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return n;
+}
+
+int mra_modality_ln(mra_qformer* h, const void* x, int32_t x_dtype, const int64_t* item_index, int32_t items,
+                    int32_t tokens, void* out, void* stream) {
+  if (!h || (!x && items > 0) || (!out && items > 0)) return fail(MRA_EINVAL, "null argument");
+  if (items < 0 || tokens < 0) return fail(MRA_EINVAL, "negative size");
+  if (items == 0 || tokens == 0) return MRA_OK;
+  if (!h->params["ln.weight"].loaded || !h->params["ln.bias"].loaded) return fail(MRA_ESTATE, "ln.weight / ln.bias not loaded");
+  return chk(launch_modality_ln(x, x_dtype, (const long long*)item_index, items, tokens, h->cfg.enc_width, h->encg,
+                                h->encb, h->cfg.enc_ln_eps, out, h->op(), as_stream(stream)),
+             "modality_ln");
+}
+
+size_t mra_qformer_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv) {
+  if (!h || items <= 0 || L < 0 || kv <= 0) return 0;
+  Work w = layout_work(h, nullptr, items, L, kv);
+  return w.bytes + align_up(attn_partial_bytes(items, h->cfg.heads, h->cfg.n_query, w.nsplit));
+}
+
+double mra_qformer_flops(mra_qformer* h, int32_t items, int32_t L, int32_t kv, int32_t with_last_text) {
+  if (!h) return 0.0;
+  const mra_cfg& c = h->cfg;
+  const double H = c.hidden, I = c.inter, E = c.enc_width, Q = c.n_query, S = Q + L, Kv = kv;
+  double per_item = c.layers * (8 * S * H * H + 4 * S * S * H + 4 * S * H * I) +
+                    h->ncross * (4 * Q * H * H + 4 * Kv * E * H + 4 * Q * Kv * H);
+  if (!with_last_text) per_item -= 4.0 * L * H * I;
+  return per_item * items;
+}
+
+int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
+                        int32_t items, int32_t L, int32_t kv, float* out_query, float* out_full, float* out_cls,
+                        void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (items < 0 || L < 0 || kv < 0) return fail(MRA_EINVAL, "negative size");
+  if (items == 0) return MRA_OK;
+  const mra_cfg& c = h->cfg;
+  if (kv == 0) return fail(MRA_EINVAL, "kv must be >= 1");
+  if (L > c.max_pos) return fail(MRA_EINVAL, "L exceeds max_pos");
+  if (!enc || (L > 0 && !input_ids)) return fail(MRA_EINVAL, "null input");
+  if (out_cls && L < 1) return fail(MRA_EINVAL, "out_cls needs L >= 1");
+  if (!out_query && !out_full && !out_cls) return fail(MRA_EINVAL, "no output requested");
+  {
+    char names[256];
+    const int miss = mra_qformer_missing(h, names, sizeof(names));
+    int tolerated = 0;
+    for (const char* opt : {"ln.weight", "ln.bias", "llm_proj.weight", "llm_proj.bias"}) {
+      auto it = h->params.find(opt);
+      if (it != h->params.end() && !it->second.loaded) ++tolerated;
+    }
+    if (miss > tolerated) return fail(MRA_ESTATE, std::string("parameters not loaded: ") + names);
+  }
+  const size_t need = mra_qformer_workspace_bytes(h, items, L, kv);
+  if (!workspace || workspace_bytes < need)
+    return fail(MRA_ENOMEM, "workspace too small: need " + std::to_string(need) + " bytes");
+  if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MRA_EINVAL, "workspace must be 256-byte aligned");
+
+  hipStream_t stream = as_stream(stream_);
+  const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter, E = c.enc_width;
+  const int op = h->op();
+  Work w = layout_work(h, (char*)workspace, N, L, kv);
+  w.part = w.nsplit > 1 ? reinterpret_cast<float*>((char*)workspace + w.bytes) : nullptr;
+  const long long SH = (long long)S * H;
+  const size_t esz = 2;
+
+  // row views of the [N, S, H] streams
+  const RowView all_rows = plain(N * S, H);
+  const RowView q_view = items_view(SH, Q, H);          // rows [:, :32]
+  const RowView t_view = items_view(SH, L > 0 ? L : 1, H);  // rows [:, 32:] (base pointer + 32*H)
+  const RowView cls_view = items_view(SH, 1, H);        // row  [:, 32]
+  const RowView qc_rows = plain(N * Q, H);              // compact [N*32, H]
+
+  // embeddings
+  int rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, c.vocab, h->query, h->word, h->pos, h->embg, h->embb,
+                           c.ln_eps, w.hA32, w.hA16, op, stream);
+  if (rc) return chk(rc, "embed_ln");
+
+  // K/V of every cross layer in one GEMM, scattered head-major
+  if (h->ncross > 0) {
+    GemmProb p{};
+    p.A = enc;
+    p.a = plain(N * kv, E);
+    p.W = h->wkv;
+    p.bias = h->bkv;
+    p.C = w.kv16;
+    p.c = plain(1, 1);
+    p.M = N * kv;
+    p.N = h->ncross * 2 * H;
+    p.K = E;
+    p.kv_tokens = kv;
+    p.kv_items = N;
+    p.kv_heads = c.heads;
+    rc = launch_gemm(&p, 1, EPI_KV, op, stream);
+    if (rc) return chk(rc, "kv projection gemm");
+  }
+
+  const bool want_text_last = out_full != nullptr;
+  const bool want_cls_last = !out_full && out_cls != nullptr;
+
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& Lw = h->layers[i];
+    const bool last = i == c.layers - 1;
+    // 1. fused Q|K|V projection of all S rows
+    {
+      GemmProb p{};
+      p.A = w.hA16; p.a = all_rows;
+      p.W = Lw.wqkv; p.bias = Lw.bqkv;
+      p.C = w.qkv16; p.c = plain(N * S, 3 * H);
+      p.M = N * S; p.N = 3 * H; p.K = H;
+      rc = launch_gemm(&p, 1, EPI_OP, op, stream);
+      if (rc) return chk(rc, "qkv gemm");
+    }
+    // 2. self-attention core
+    {
+      AttnArgs a{};
+      a.Q = w.qkv16;
+      a.K = w.qkv16 + (size_t)H * esz;
+      a.V = w.qkv16 + (size_t)2 * H * esz;
+      a.O = w.ctx16;
+      a.q_item_stride = (long long)S * 3 * H; a.q_ld = 3 * H;
+      a.k_item_stride = (long long)S * 3 * H; a.k_head_stride = 64; a.k_ld = 3 * H;
+      a.v_item_stride = (long long)S * 3 * H; a.v_head_stride = 64; a.v_ld = 3 * H;
+      a.o_item_stride = SH; a.o_ld = H;
+      a.mask = (const long long*)attention_mask; a.mask_ld = S;
+      a.items = N; a.heads = c.heads; a.q_rows = S; a.kv_len = S;
+      a.scale = 0.125f; a.nsplit = 1; a.part = nullptr;
+      rc = launch_attention(a, op, stream);
+      if (rc) return chk(rc, "self attention");
+    }
+    // 3. output projection + residual, 4. LayerNorm -> hB
+    {
+      GemmProb p{};
+      p.A = w.ctx16; p.a = all_rows;
+      p.W = Lw.wo; p.bias = Lw.bo;
+      p.R = w.hA32; p.r = all_rows;
+      p.C = w.pre32; p.c = all_rows;
+      p.M = N * S; p.N = H; p.K = H;
+      rc = launch_gemm(&p, 1, EPI_RES_F32, op, stream);
+      if (rc) return chk(rc, "attn out gemm");
+      rc = launch_ln_rows(w.pre32, all_rows, N * S, H, Lw.ln1g, Lw.ln1b, c.ln_eps, w.hB32, all_rows, w.hB16, all_rows, op,
+                          stream);
+      if (rc) return chk(rc, "attn ln");
+    }
+    // query-side state entering the feed-forward: hB[:, :32] or the cross-attention output hC
+    const void* fq16 = w.hB16;
+    const float* fq32 = w.hB32;
+    RowView fqv = q_view;
+    if (Lw.cross_index >= 0) {
+      // 5. cross query projection
+      GemmProb p{};
+      p.A = w.hB16; p.a = q_view;
+      p.W = Lw.wcq; p.bias = Lw.bcq;
+      p.C = w.qc16; p.c = qc_rows;
+      p.M = N * Q; p.N = H; p.K = H;
+      rc = launch_gemm(&p, 1, EPI_OP, op, stream);
+      if (rc) return chk(rc, "cross q gemm");
+      // 6. cross-attention core over the head-major K/V cache
+      AttnArgs a{};
+      const size_t per_sel = (size_t)N * c.heads * kv * 64;
+      a.Q = w.qc16;
+      a.K = w.kv16 + (size_t)(Lw.cross_index * 2 + 0) * per_sel * esz;
+      a.V = w.kv16 + (size_t)(Lw.cross_index * 2 + 1) * per_sel * esz;
+      a.O = w.ctx16;
+      a.q_item_stride = (long long)Q * H; a.q_ld = H;
+      a.k_item_stride = (long long)c.heads * kv * 64; a.k_head_stride = (long long)kv * 64; a.k_ld = 64;
+      a.v_item_stride = a.k_item_stride; a.v_head_stride = a.k_head_stride; a.v_ld = 64;
+      a.o_item_stride = (long long)Q * H; a.o_ld = H;
+      a.mask = nullptr; a.mask_ld = 0;
+      a.items = N; a.heads = c.heads; a.q_rows = Q; a.kv_len = kv;
+      a.scale = 0.125f; a.nsplit = w.nsplit; a.part = w.part;
+      rc = launch_attention(a, op, stream);
+      if (rc) return chk(rc, "cross attention");
+      // 7. output projection + residual (hB[:, :32]), 8. LayerNorm -> hC (compact)
+      GemmProb o{};
+      o.A = w.ctx16; o.a = qc_rows;
+      o.W = Lw.wco; o.bias = Lw.bco;
+      o.R = w.hB32; o.r = q_view;
+      o.C = w.pre32; o.c = qc_rows;
+      o.M = N * Q; o.N = H; o.K = H;
+      rc = launch_gemm(&o, 1, EPI_RES_F32, op, stream);
+      if (rc) return chk(rc, "cross out gemm");
+      rc = launch_ln_rows(w.pre32, qc_rows, N * Q, H, Lw.lncg, Lw.lncb, c.ln_eps, w.hC32, qc_rows, w.hC16, qc_rows, op,
+                          stream);
+      if (rc) return chk(rc, "cross ln");
+      fq16 = w.hC16;
+      fq32 = w.hC32;
+      fqv = qc_rows;
+    }
+    // 9-14. feed-forwards: group 0 = query rows, group 1 = text rows (own weights)
+    int text_rows = 0;
+    RowView tv = t_view;
+    if (L > 0) {
+      if (!last || want_text_last) text_rows = N * L;
+      else if (want_cls_last) { text_rows = N; tv = cls_view; }
+    }
+    const size_t t_off16 = (size_t)Q * H * esz;   // byte offset of row 32 inside an item (op dtype)
+    const size_t t_off32 = (size_t)Q * H;         // element offset (f32)
+    {
+      GemmProb g[2] = {};
+      g[0].A = fq16; g[0].a = fqv;
+      g[0].W = Lw.wiq; g[0].bias = Lw.biq;
+      g[0].C = w.ffn16; g[0].c = plain(N * Q, I);
+      g[0].M = N * Q; g[0].N = I; g[0].K = H;
+      g[1].A = w.hB16 + t_off16; g[1].a = tv;
+      g[1].W = Lw.wit; g[1].bias = Lw.bit;
+      g[1].C = w.ffn16 + (size_t)N * Q * I * esz; g[1].c = plain(text_rows, I);
+      g[1].M = text_rows; g[1].N = I; g[1].K = H;
+      rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_GELU_OP, op, stream);
+      if (rc) return chk(rc, "ffn up gemm");
+    }
+    {
+      GemmProb g[2] = {};
+      g[0].A = w.ffn16; g[0].a = plain(N * Q, I);
+      g[0].W = Lw.woq; g[0].bias = Lw.boq;
+      g[0].R = fq32; g[0].r = fqv;
+      g[0].C = w.pre32; g[0].c = q_view;
+      g[0].M = N * Q; g[0].N = H; g[0].K = I;
+      g[1].A = w.ffn16 + (size_t)N * Q * I * esz; g[1].a = plain(text_rows, I);
+      g[1].W = Lw.wot; g[1].bias = Lw.bot;
+      g[1].R = w.hB32 + t_off32; g[1].r = tv;
+      g[1].C = w.pre32 + t_off32; g[1].c = tv;
+      g[1].M = text_rows; g[1].N = H; g[1].K = I;
+      rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_F32, op, stream);
+      if (rc) return chk(rc, "ffn down gemm");
+    }
+    if (!last) {
+      rc = launch_ln_rows(w.pre32, q_view, N * Q, H, Lw.lnqg, Lw.lnqb, c.ln_eps, w.hA32, q_view, w.hA16, q_view, op, stream);
+      if (rc) return chk(rc, "ffn query ln");
+      if (text_rows > 0) {
+        rc = launch_ln_rows(w.pre32 + t_off32, tv, text_rows, H, Lw.lntg, Lw.lntb, c.ln_eps, w.hA32 + t_off32, tv,
+                            w.hA16 + t_off16, tv, op, stream);
+        if (rc) return chk(rc, "ffn text ln");
+      }
+    } else {
+      // last layer: LayerNorm straight into the caller's buffers
+      if (out_full) {
+        rc = launch_ln_rows(w.pre32, q_view, N * Q, H, Lw.lnqg, Lw.lnqb, c.ln_eps, out_full, q_view, nullptr, q_view, op, stream);
+        if (rc) return chk(rc, "final query ln");
+        if (text_rows > 0) {
+          rc = launch_ln_rows(w.pre32 + t_off32, tv, text_rows, H, Lw.lntg, Lw.lntb, c.ln_eps, out_full + t_off32, tv, nullptr,
+                              tv, op, stream);
+          if (rc) return chk(rc, "final text ln");
+        }
+        if (out_query) {
+          rc = launch_copy_rows_f32(out_full, q_view, out_query, qc_rows, N * Q, H, stream);
+          if (rc) return chk(rc, "copy out_query");
+        }
+        if (out_cls) {
+          rc = launch_copy_rows_f32(out_full + t_off32, cls_view, out_cls, plain(N, H), N, H, stream);
+          if (rc) return chk(rc, "copy out_cls");
+        }
+      } else {
+        if (out_query) {
+          rc = launch_ln_rows(w.pre32, q_view, N * Q, H, Lw.lnqg, Lw.lnqb, c.ln_eps, out_query, qc_rows, nullptr, qc_rows, op,
+                              stream);
+          if (rc) return chk(rc, "final query ln");
+        }
+        if (out_cls) {
+          rc = launch_ln_rows(w.pre32 + t_off32, cls_view, N, H, Lw.lntg, Lw.lntb, c.ln_eps, out_cls, plain(N, H), nullptr,
+                              plain(N, H), op, stream);
+          if (rc) return chk(rc, "final cls ln");
+        }
+      }
+    }
+  }
+  return MRA_OK;
+}
+
+int mra_llm_proj(mra_qformer* h, const float* z, int32_t rows, void* out, int32_t out_dtype, void* workspace,
+                 size_t workspace_bytes, void* stream_) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (rows < 0) return fail(MRA_EINVAL, "negative rows");
+  if (rows == 0) return MRA_OK;
+  const mra_cfg& c = h->cfg;
+  if (c.llm_hidden <= 0 || !h->params["llm_proj.weight"].loaded || !h->params["llm_proj.bias"].loaded)
+    return fail(MRA_ESTATE, "llm_proj not loaded");
+  if (!z || !out || !workspace) return fail(MRA_EINVAL, "null argument");
+  const size_t need = align_up((size_t)rows * c.hidden * 2);
+  if (workspace_bytes < need) return fail(MRA_ENOMEM, "workspace too small: need " + std::to_string(need));
+  const int op = h->op();
+  if (out_dtype != MRA_F32 && out_dtype != c.op_dtype) return fail(MRA_EINVAL, "out_dtype must be f32 or the operand dtype");
+  hipStream_t stream = as_stream(stream_);
+  int rc = launch_convert(z, MRA_F32, workspace, c.op_dtype, (long long)rows * c.hidden, stream);
+  if (rc) return chk(rc, "convert z");
+  GemmProb p{};
+  p.A = workspace; p.a = plain(rows, c.hidden);
+  p.W = h->wllm; p.bias = h->bllm;
+  p.C = out; p.c = plain(rows, c.llm_hidden);
+  p.M = rows; p.N = c.llm_hidden; p.K = c.hidden;
+  return chk(launch_gemm(&p, 1, out_dtype == MRA_F32 ? EPI_F32 : EPI_OP, op, stream), "llm_proj gemm");
+}
+
+int mra_cosine_score(const float* z, const float* t, int32_t t_rows, int32_t items, int32_t n_query, int32_t hidden,
+                     float* sim, float* logit, void* stream) {
+  if (items < 0) return fail(MRA_EINVAL, "negative items");
+  if (items == 0) return MRA_OK;
+  if (!z || !t || !logit) return fail(MRA_EINVAL, "null argument");
+  return chk(launch_cosine_score(z, t, t_rows, items, n_query, hidden, 1e-8f, sim, logit, as_stream(stream)), "cosine_score");
+}
+
+int mra_fuse_logits(const float* const* logits, const float* weights, int32_t nmod, int32_t n, float* out, void* stream) {
+  if (n < 0) return fail(MRA_EINVAL, "negative n");
+  if (!logits || !out) return fail(MRA_EINVAL, "null argument");
+  for (int m = 0; m < nmod && m < 4; ++m)
+    if (!logits[m]) return fail(MRA_EINVAL, "null logits pointer");
+  return chk(launch_fuse_logits(logits, weights, nmod, n, out, as_stream(stream)), "fuse_logits");
+}
+
+int mra_span_from_logits(const float* logits, int32_t videos, int32_t clips, float alpha, int32_t* spans, void* stream) {
+  if (videos < 0) return fail(MRA_EINVAL, "negative videos");
+  if (videos == 0) return MRA_OK;
+  if (!logits || !spans) return fail(MRA_EINVAL, "null argument");
+  return chk(launch_span(logits, videos, clips, alpha, spans, as_stream(stream)), "span_from_logits");
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+// HBM-bound row kernels: LayerNorms, embeddings, dtype conversion.  One wave per row, 16-byte
+// accesses, two-pass (mean, then centred variance) statistics in fp32 held in registers.
+//
+//   ln_rows_kernel       BERT LayerNorm (eps 1e-12) after every residual add of the Q-Former
+//                        (HF modeling_instructblip.py:519-530,573-587); writes the fp32 residual
+//                        stream and the op-dtype copy the next GEMM reads.
+//   modality_ln_kernel   reference models/xinstructblip.py:822-828 (fp32 LayerNorm, eps 1e-5) fused
+//                        with the sample-major gather of models/xinstructblip.py:281-285.
+//   embed_ln_kernel      Q-Former embeddings (HF modeling_instructblip.py:728-757): queries as is,
+//                        text = word + absolute position, then LayerNorm.
+#include "kernels.h"
+#include "mra_common.h"
+
+namespace mra {
+
+namespace {
+
+__device__ __forceinline__ long long vrow(const RowView& v, int m) {
+  const int item = m / v.rpi;
+  return (long long)item * v.item_stride + (long long)(m - item * v.rpi) * v.ld;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, f32x4 v) {
+  typename Vec4<T>::type o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+  *reinterpret_cast<typename Vec4<T>::type*>(p) = o;
+}
+
+// NV = float4 per lane; H = 256 * NV
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) ln_rows_kernel(const float* x, RowView xv, int rows, const float* gain,
+                                                      const float* bias, float eps, float* y32, RowView y32v, T* y16,
+                                                      RowView y16v) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int H = NV * 256;
+  const float* xr = x + vrow(xv, row);
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + eps);
+  float* o32 = y32 ? y32 + vrow(y32v, row) : nullptr;
+  T* o16 = y16 ? y16 + vrow(y16v, row) : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rstd * g[e] + b[e];
+    if (o32) *reinterpret_cast<f32x4*>(o32 + c) = y;
+    if (o16) store4<T>(o16 + c, y);
+  }
+}
+
+template <typename TI>
+__device__ __forceinline__ f32x4 load4(const TI* p);
+template <>
+__device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
+  const Vec4<f16>::type h = *reinterpret_cast<const Vec4<f16>::type*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <>
+__device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+  const Vec4<bf16>::type h = *reinterpret_cast<const Vec4<bf16>::type*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+// rows of E (multiple of 4, <= 256 * MAXV) elements; out item i <- in item index[i]
+template <typename TI, typename TO, int MAXV>
+__global__ void __launch_bounds__(256) modality_ln_kernel(const TI* x, const long long* index, int items, int tokens,
+                                                          int E, const float* gain, const float* bias, float eps,
+                                                          TO* out) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)items * tokens) return;
+  const int item = (int)(row / tokens);
+  const int tok = (int)(row - (long long)item * tokens);
+  const long long src_item = index ? index[item] : item;
+  const TI* xr = x + (src_item * tokens + tok) * E;
+  const int nv = E >> 2;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      v[i] = load4<TI>(xr + c * 4);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+  TO* orow = out + row * E;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c * 4);
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rstd * g[e] + b[e];
+      store4<TO>(orow + c * 4, y);
+    }
+  }
+}
+
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) embed_ln_kernel(const long long* ids, int items, int L, int Q, int vocab,
+                                                       const float* query, const float* word, const float* pos,
+                                                       const float* gain, const float* bias, float eps, float* h32,
+                                                       T* h16) {
+  constexpr int H = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int S = Q + L;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)items * S) return;
+  const int item = (int)(row / S);
+  const int s = (int)(row - (long long)item * S);
+  f32x4 v[NV];
+  float sum = 0.f;
+  if (s < Q) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(query + (long long)s * H + (i * 64 + lane) * 4);
+  } else {
+    long long id = ids[(long long)item * L + (s - Q)];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never fault on a bad token id
+    const float* wr = word + id * H;
+    const float* pr = pos + (long long)(s - Q) * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      v[i] = *reinterpret_cast<const f32x4*>(wr + c) + *reinterpret_cast<const f32x4*>(pr + c);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(sum) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rstd * g[e] + b[e];
+    *reinterpret_cast<f32x4*>(h32 + row * H + c) = y;
+    store4<T>(h16 + row * H + c, y);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) convert_kernel(const TI* src, TO* dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = load4<TI>(src + i * 4);
+    if constexpr (sizeof(TO) == 4) {
+      *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    } else {
+      store4<TO>(dst + i * 4, v);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* src, RowView sv, float* dst, RowView dv, int rows,
+                                                        int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = src + vrow(sv, row);
+  float* d = dst + vrow(dv, row);
+  for (int c = lane * 4; c < H; c += 256) *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
+}
+
+template <typename TI, typename TO>
+int modality_ln_t(const void* x, const long long* index, int items, int tokens, int E, const float* gain,
+                  const float* bias, float eps, void* out, hipStream_t stream) {
+  const long long rows = (long long)items * tokens;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (E <= 1024) {
+    hipLaunchKernelGGL((modality_ln_kernel<TI, TO, 4>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, index, items,
+                       tokens, E, gain, bias, eps, (TO*)out);
+  } else if (E <= 1536) {
+    hipLaunchKernelGGL((modality_ln_kernel<TI, TO, 6>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, index, items,
+                       tokens, E, gain, bias, eps, (TO*)out);
+  } else if (E <= 4096) {
+    hipLaunchKernelGGL((modality_ln_kernel<TI, TO, 16>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, index, items,
+                       tokens, E, gain, bias, eps, (TO*)out);
+  } else {
+    return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <typename TO>
+int modality_ln_o(const void* x, int x_dtype, const long long* index, int items, int tokens, int E, const float* gain,
+                  const float* bias, float eps, void* out, hipStream_t stream) {
+  switch (x_dtype) {
+    case 0: return modality_ln_t<float, TO>(x, index, items, tokens, E, gain, bias, eps, out, stream);
+    case 1: return modality_ln_t<f16, TO>(x, index, items, tokens, E, gain, bias, eps, out, stream);
+    case 2: return modality_ln_t<bf16, TO>(x, index, items, tokens, E, gain, bias, eps, out, stream);
+  }
+  return -2;
+}
+
+template <typename TI>
+int convert_i(const void* src, void* dst, int dst_dtype, long long n, hipStream_t stream) {
+  const long long n4 = n / 4;
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  if (blocks == 0) return 0;
+  switch (dst_dtype) {
+    case 0: hipLaunchKernelGGL((convert_kernel<TI, float>), dim3(blocks), dim3(256), 0, stream, (const TI*)src, (float*)dst, n4); break;
+    case 1: hipLaunchKernelGGL((convert_kernel<TI, f16>), dim3(blocks), dim3(256), 0, stream, (const TI*)src, (f16*)dst, n4); break;
+    case 2: hipLaunchKernelGGL((convert_kernel<TI, bf16>), dim3(blocks), dim3(256), 0, stream, (const TI*)src, (bf16*)dst, n4); break;
+    default: return -2;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace
+
+int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, float eps,
+                   float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (H % 256 || H > 1024 || H <= 0) return -1;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define MRA_LN_CASE(T, NV)                                                                                         \
+  hipLaunchKernelGGL((ln_rows_kernel<T, NV>), grid, block, 0, stream, x, xv, rows, gain, bias, eps, y32, y32v, \
+                     (T*)y16, y16v)
+  const int nv = H / 256;
+  if (op_dtype == OP_F16) {
+    if (nv == 1) MRA_LN_CASE(f16, 1); else if (nv == 2) MRA_LN_CASE(f16, 2); else if (nv == 3) MRA_LN_CASE(f16, 3); else MRA_LN_CASE(f16, 4);
+  } else {
+    if (nv == 1) MRA_LN_CASE(bf16, 1); else if (nv == 2) MRA_LN_CASE(bf16, 2); else if (nv == 3) MRA_LN_CASE(bf16, 3); else MRA_LN_CASE(bf16, 4);
+  }
+#undef MRA_LN_CASE
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, int items, int tokens, int E,
+                       const float* gain, const float* bias, float eps, void* out, int op_dtype, hipStream_t stream) {
+  if (items <= 0 || tokens <= 0) return 0;
+  if (E % 4 || E <= 0) return -1;
+  return op_dtype == OP_F16
+             ? modality_ln_o<f16>(x, x_dtype, item_index, items, tokens, E, gain, bias, eps, out, stream)
+             : modality_ln_o<bf16>(x, x_dtype, item_index, items, tokens, E, gain, bias, eps, out, stream);
+}
+
+int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query,
+                    const float* word, const float* pos, const float* gain, const float* bias, float eps, float* h32,
+                    void* h16, int op_dtype, hipStream_t stream) {
+  if (items <= 0) return 0;
+  if (H % 256 || H > 1024 || H <= 0 || L < 0 || Q < 0) return -1;
+  const long long rows = (long long)items * (Q + L);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define MRA_EM_CASE(T, NV)                                                                                        \
+  hipLaunchKernelGGL((embed_ln_kernel<T, NV>), grid, block, 0, stream, ids, items, L, Q, vocab, query, word, pos, \
+                     gain, bias, eps, h32, (T*)h16)
+  const int nv = H / 256;
+  if (op_dtype == OP_F16) {
+    if (nv == 1) MRA_EM_CASE(f16, 1); else if (nv == 2) MRA_EM_CASE(f16, 2); else if (nv == 3) MRA_EM_CASE(f16, 3); else MRA_EM_CASE(f16, 4);
+  } else {
+    if (nv == 1) MRA_EM_CASE(bf16, 1); else if (nv == 2) MRA_EM_CASE(bf16, 2); else if (nv == 3) MRA_EM_CASE(bf16, 3); else MRA_EM_CASE(bf16, 4);
+  }
+#undef MRA_EM_CASE
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, hipStream_t stream) {
+  if (n % 4) return -1;
+  switch (src_dtype) {
+    case 0: return convert_i<float>(src, dst, dst_dtype, n, stream);
+    case 1: return convert_i<f16>(src, dst, dst_dtype, n, stream);
+    case 2: return convert_i<bf16>(src, dst, dst_dtype, n, stream);
+  }
+  return -2;
+}
+
+int launch_copy_rows_f32(const float* src, RowView sv, float* dst, RowView dv, int rows, int H, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (H % 4) return -1;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, src, sv, dst, dv, rows, H);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace mra

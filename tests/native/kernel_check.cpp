@@ -1,0 +1,509 @@
+// Standalone GPU self-check of the gfx950 kernels against straightforward host loops.
+// Test infrastructure: links libmra_hip.so, runs in seconds, no Python.  `kernel_check [quick]`.
+// Every case prints one line "ok|FAIL name max_err tol"; exit code = number of failed cases.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "mra.h"
+
+using namespace mra;
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(99);                                                                            \
+    }                                                                                      \
+  } while (0)
+
+static int g_fail = 0;
+static std::mt19937 g_rng(1234);
+
+static float frand(float s = 1.f) {
+  std::normal_distribution<float> d(0.f, s);
+  return d(g_rng);
+}
+
+// operand-dtype helpers on the host
+static uint16_t to_op(float x, int op) {
+  if (op == OP_F16) {
+    _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+  }
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16;  // finite inputs only
+  return (uint16_t)u;
+}
+static float from_op(uint16_t v, int op) {
+  if (op == OP_F16) {
+    _Float16 h;
+    memcpy(&h, &v, 2);
+    return (float)h;
+  }
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+template <typename T>
+struct Dev {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit Dev(size_t n_) : n(n_) { CK(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T))); }
+  Dev(const std::vector<T>& h) : n(h.size()) {
+    CK(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+    CK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  ~Dev() { (void)hipFree(p); }
+  std::vector<T> get() const {
+    std::vector<T> h(n);
+    CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+  void fill(int byte) { CK(hipMemset(p, byte, n * sizeof(T))); }
+};
+
+static void report(const std::string& name, double err, double tol) {
+  const bool ok = err <= tol && std::isfinite(err);
+  if (!ok) ++g_fail;
+  printf("%s %-58s err %.3e tol %.1e\n", ok ? "ok  " : "FAIL", name.c_str(), err, tol);
+  fflush(stdout);
+}
+
+static long long voff(const RowView& v, int m) { return (long long)(m / v.rpi) * v.item_stride + (long long)(m % v.rpi) * v.ld; }
+
+// ------------------------------------------------------------------------------------------------
+static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views, int groups = 1) {
+  gemm_force_config(cfg);
+  // activations live in [items, S, K] with the rows of interest at [:, off:off+rpi]
+  const int rpi = views ? 5 : (M > 0 ? M : 1);
+  const int S = views ? 9 : rpi, off = views ? 3 : 0;
+  const int items = (M + rpi - 1) / rpi;
+  struct G {
+    std::vector<uint16_t> A, W;
+    std::vector<float> bias, R;
+    RowView av, cv, rv;
+    size_t csz;
+  };
+  std::vector<G> g(groups);
+  std::vector<Dev<uint16_t>*> dA, dW, dC16;
+  std::vector<Dev<float>*> dB, dR, dC32;
+  std::vector<GemmProb> probs(groups);
+  const int kvtok = 7, heads = N >= 128 ? 2 : 1;  // EPI_KV: hidden = heads*64, N = sel*hidden
+  for (int q = 0; q < groups; ++q) {
+    G& x = g[q];
+    x.A.resize((size_t)items * S * K);
+    for (auto& v : x.A) v = to_op(frand(), op);
+    x.W.resize((size_t)N * K);
+    for (auto& v : x.W) v = to_op(frand(0.05f), op);
+    x.bias.resize(N);
+    for (auto& v : x.bias) v = frand(0.5f);
+    x.av = RowView{(long long)S * K, rpi, K};
+    const int ldc = N + (views ? 8 : 0);
+    x.cv = RowView{(long long)S * ldc, rpi, ldc};
+    x.rv = RowView{(long long)S * N, rpi, N};
+    x.R.resize((size_t)items * S * N);
+    for (auto& v : x.R) v = frand();
+    x.csz = (size_t)items * S * ldc;
+    dA.push_back(new Dev<uint16_t>(x.A));
+    dW.push_back(new Dev<uint16_t>(x.W));
+    dB.push_back(new Dev<float>(x.bias));
+    dR.push_back(new Dev<float>(x.R));
+    const size_t kvsz = (size_t)N * ((M + kvtok - 1) / kvtok) * kvtok;
+    dC16.push_back(new Dev<uint16_t>(epi == EPI_KV ? kvsz : x.csz));
+    dC32.push_back(new Dev<float>(x.csz));
+    dC16.back()->fill(0xFF);
+    dC32.back()->fill(0xFF);
+    GemmProb& p = probs[q];
+    memset(&p, 0, sizeof(p));
+    p.A = dA[q]->p + (size_t)off * K;
+    p.a = x.av;
+    p.W = dW[q]->p;
+    p.bias = dB[q]->p;
+    p.M = q == 0 ? M : (M > 3 ? M - 3 : M);
+    p.N = N;
+    p.K = K;
+    if (epi == EPI_RES_F32 || epi == EPI_F32) {
+      p.C = dC32[q]->p + (size_t)off * ldc;
+      p.c = x.cv;
+      p.R = dR[q]->p + (size_t)off * N;
+      p.r = x.rv;
+    } else if (epi == EPI_KV) {
+      p.C = dC16[q]->p;
+      p.c = RowView{0, 1, 1};
+      p.kv_tokens = kvtok;
+      p.kv_items = (M + kvtok - 1) / kvtok;
+      p.kv_heads = heads;
+    } else {
+      p.C = dC16[q]->p + (size_t)off * ldc;
+      p.c = x.cv;
+    }
+  }
+  const int rc = launch_gemm(probs.data(), groups, epi, op, 0);
+  CK(hipDeviceSynchronize());
+  double worst = rc == 0 ? 0.0 : 1e30;
+  for (int q = 0; q < groups && rc == 0; ++q) {
+    const GemmProb& p = probs[q];
+    G& x = g[q];
+    std::vector<uint16_t> c16 = dC16[q]->get();
+    std::vector<float> c32 = dC32[q]->get();
+    const int ldc = x.cv.ld;
+    for (int m = 0; m < p.M; ++m) {
+      const uint16_t* ar = x.A.data() + (size_t)off * K + voff(x.av, m);
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        const uint16_t* wr = x.W.data() + (size_t)n * K;
+        for (int k = 0; k < K; ++k) acc += (double)from_op(ar[k], op) * (double)from_op(wr[k], op);
+        acc += x.bias[n];
+        double got;
+        if (epi == EPI_GELU_OP) acc = 0.5 * acc * (1.0 + erf(acc / sqrt(2.0)));
+        if (epi == EPI_RES_F32) acc += x.R[(size_t)off * N + voff(x.rv, m) + n];
+        if (epi == EPI_RES_F32 || epi == EPI_F32) {
+          got = c32[(size_t)off * ldc + voff(x.cv, m) + n];
+        } else if (epi == EPI_KV) {
+          const int hidden = heads * 64, sel = n / hidden, within = n % hidden, head = within / 64, d = within % 64;
+          const int item = m / kvtok, tok = m % kvtok;
+          const size_t dst = ((((size_t)sel * p.kv_items + item) * heads + head) * kvtok + tok) * 64 + d;
+          got = from_op(c16[dst], op);
+        } else {
+          got = from_op(c16[(size_t)off * ldc + voff(x.cv, m) + n], op);
+        }
+        const double err = fabs(got - acc) / (1.0 + fabs(acc));
+        worst = std::isfinite(err) ? std::max(worst, err) : 1e30;
+      }
+    }
+  }
+  char name[160];
+  snprintf(name, sizeof(name), "gemm cfg%d epi%d %s M%d N%d K%d views%d groups%d", cfg, epi, op == OP_F16 ? "f16" : "bf16", M, N, K,
+           (int)views, groups);
+  const bool lowp_out = epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_KV;
+  report(name, worst, op == OP_F16 ? (lowp_out ? 2e-3 : 5e-4) : (lowp_out ? 1.2e-2 : 4e-3));
+  for (auto p : dA) delete p;
+  for (auto p : dW) delete p;
+  for (auto p : dB) delete p;
+  for (auto p : dR) delete p;
+  for (auto p : dC16) delete p;
+  for (auto p : dC32) delete p;
+  gemm_force_config(-1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention: self (packed QKV rows, ragged mask) or cross (head-major cache)
+static void test_attention(int op, int items, int heads, int q_rows, int kv_len, bool self, int nsplit, bool spike = false) {
+  const int H = heads * 64;
+  std::vector<uint16_t> Q, K, V;
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  std::vector<long long> mask;
+  const int ldqkv = 3 * H;
+  if (self) {
+    Q.resize((size_t)items * q_rows * ldqkv);
+    for (auto& v : Q) v = to_op(frand(1.5f), op);
+    mask.resize((size_t)items * kv_len, 1);
+    for (int n = 0; n < items; ++n) {
+      const int valid = 32 + (n * 7) % (kv_len - 32 + 1);  // the 32 queries are never masked
+      for (int t = valid; t < kv_len; ++t) mask[(size_t)n * kv_len + t] = 0;
+    }
+  } else {
+    Q.resize((size_t)items * q_rows * H);
+    K.resize((size_t)items * heads * kv_len * 64);
+    V.resize(K.size());
+    for (auto& v : Q) v = to_op(frand(1.5f), op);
+    for (auto& v : K) v = to_op(frand(1.5f), op);
+    for (auto& v : V) v = to_op(frand(), op);
+    if (spike) {  // force a late, large running-max jump (online-softmax rescale path)
+      for (int d = 0; d < 64; ++d) {
+        const size_t kidx = ((size_t)0 * heads + 0) * kv_len * 64 + (size_t)(kv_len - 5) * 64 + d;
+        K[kidx] = to_op(from_op(Q[(size_t)3 * H + d], op) * 3.0f, op);
+      }
+    }
+  }
+  Dev<uint16_t> dQ(Q), dK(K), dV(V);
+  Dev<long long> dM(mask);
+  Dev<uint16_t> dO((size_t)items * q_rows * H);
+  dO.fill(0xFF);
+  Dev<float> dP(attn_partial_bytes(items, heads, q_rows, nsplit) / 4 + 4);
+  a.Q = dQ.p;
+  a.O = dO.p;
+  a.o_item_stride = (long long)q_rows * H;
+  a.o_ld = H;
+  if (self) {
+    a.K = dQ.p + H;
+    a.V = dQ.p + 2 * H;
+    a.q_item_stride = a.k_item_stride = a.v_item_stride = (long long)q_rows * ldqkv;
+    a.q_ld = a.k_ld = a.v_ld = ldqkv;
+    a.k_head_stride = a.v_head_stride = 64;
+    a.mask = dM.p;
+    a.mask_ld = kv_len;
+  } else {
+    a.K = dK.p;
+    a.V = dV.p;
+    a.q_item_stride = (long long)q_rows * H;
+    a.q_ld = H;
+    a.k_item_stride = a.v_item_stride = (long long)heads * kv_len * 64;
+    a.k_head_stride = a.v_head_stride = (long long)kv_len * 64;
+    a.k_ld = a.v_ld = 64;
+  }
+  a.items = items;
+  a.heads = heads;
+  a.q_rows = q_rows;
+  a.kv_len = kv_len;
+  a.scale = 0.125f;
+  a.nsplit = nsplit;
+  a.part = nsplit > 1 ? dP.p : nullptr;
+  const int rc = launch_attention(a, op, 0);
+  CK(hipDeviceSynchronize());
+  double worst = rc == 0 ? 0.0 : 1e30;
+  if (rc == 0) {
+    std::vector<uint16_t> O = dO.get();
+    std::vector<double> s(kv_len);
+    for (int n = 0; n < items; ++n)
+      for (int h = 0; h < heads; ++h)
+        for (int q = 0; q < q_rows; ++q) {
+          const uint16_t* qp = self ? Q.data() + ((size_t)n * q_rows + q) * ldqkv + h * 64 : Q.data() + ((size_t)n * q_rows + q) * H + h * 64;
+          double mx = -1e300;
+          for (int t = 0; t < kv_len; ++t) {
+            const uint16_t* kp = self ? Q.data() + ((size_t)n * q_rows + t) * ldqkv + H + h * 64
+                                      : K.data() + (((size_t)n * heads + h) * kv_len + t) * 64;
+            double acc = 0;
+            for (int d = 0; d < 64; ++d) acc += (double)from_op(qp[d], op) * from_op(kp[d], op);
+            acc *= 0.125;
+            if (self) acc += (1.0 - (double)mask[(size_t)n * kv_len + t]) * -10000.0;
+            s[t] = acc;
+            mx = std::max(mx, acc);
+          }
+          double den = 0;
+          for (int t = 0; t < kv_len; ++t) { s[t] = exp(s[t] - mx); den += s[t]; }
+          for (int d = 0; d < 64; ++d) {
+            double acc = 0;
+            for (int t = 0; t < kv_len; ++t) {
+              const uint16_t* vp = self ? Q.data() + ((size_t)n * q_rows + t) * ldqkv + 2 * H + h * 64
+                                        : V.data() + (((size_t)n * heads + h) * kv_len + t) * 64;
+              acc += s[t] * from_op(vp[d], op);
+            }
+            acc /= den;
+            const double got = from_op(O[((size_t)n * q_rows + q) * H + h * 64 + d], op);
+            const double err = fabs(got - acc);
+            worst = std::isfinite(err) ? std::max(worst, err) : 1e30;
+          }
+        }
+  }
+  char name[160];
+  snprintf(name, sizeof(name), "attention %s %s items%d heads%d q%d kv%d split%d%s", self ? "self" : "cross", op == OP_F16 ? "f16" : "bf16",
+           items, heads, q_rows, kv_len, nsplit, spike ? " spike" : "");
+  report(name, worst, op == OP_F16 ? 3e-3 : 2e-2);
+}
+
+// ------------------------------------------------------------------------------------------------
+static void test_ln_rows(int op) {
+  const int items = 5, S = 9, H = 768, rpi = 4, off = 2;
+  std::vector<float> x((size_t)items * S * H), g(H), b(H);
+  for (auto& v : x) v = frand(2.f) + 0.7f;
+  for (auto& v : g) v = 1.f + frand(0.1f);
+  for (auto& v : b) v = frand(0.1f);
+  Dev<float> dx(x), dg(g), db(b), dy((size_t)items * S * H);
+  Dev<uint16_t> dy16((size_t)items * rpi * H);
+  dy.fill(0);
+  RowView v{(long long)S * H, rpi, H}, c{0, items * rpi, H};
+  int rc = launch_ln_rows(dx.p + off * H, v, items * rpi, H, dg.p, db.p, 1e-12f, dy.p + off * H, v, dy16.p, c, op, 0);
+  CK(hipDeviceSynchronize());
+  double worst = rc ? 1e30 : 0, worst16 = rc ? 1e30 : 0;
+  std::vector<float> y = dy.get();
+  std::vector<uint16_t> y16 = dy16.get();
+  for (int m = 0; m < items * rpi && !rc; ++m) {
+    const float* xr = x.data() + off * H + voff(v, m);
+    double mu = 0, var = 0;
+    for (int i = 0; i < H; ++i) mu += xr[i];
+    mu /= H;
+    for (int i = 0; i < H; ++i) var += (xr[i] - mu) * (xr[i] - mu);
+    var /= H;
+    for (int i = 0; i < H; ++i) {
+      const double ref = (xr[i] - mu) / sqrt(var + 1e-12) * g[i] + b[i];
+      worst = std::max(worst, fabs(ref - y[off * H + voff(v, m) + i]));
+      worst16 = std::max(worst16, fabs(ref - from_op(y16[(size_t)m * H + i], op)) / (1 + fabs(ref)));
+    }
+  }
+  report(std::string("ln_rows f32 out ") + (op == OP_F16 ? "f16" : "bf16"), worst, 2e-5);
+  report("ln_rows op-dtype copy", worst16, op == OP_F16 ? 1e-3 : 8e-3);
+}
+
+static void test_modality_ln(int x_dtype, int E) {
+  const int src_items = 4, items = 6, tokens = 5;
+  std::vector<float> xf((size_t)src_items * tokens * E), g(E), b(E);
+  for (auto& v : xf) v = frand(3.f) - 1.f;
+  for (auto& v : g) v = 1.f + frand(0.1f);
+  for (auto& v : b) v = frand(0.1f);
+  std::vector<long long> idx = {3, 0, 2, 2, 1, 0};
+  std::vector<uint16_t> x16(xf.size());
+  if (x_dtype != 0)
+    for (size_t i = 0; i < xf.size(); ++i) {
+      x16[i] = to_op(xf[i], x_dtype == 1 ? OP_F16 : OP_BF16);
+      xf[i] = from_op(x16[i], x_dtype == 1 ? OP_F16 : OP_BF16);
+    }
+  Dev<float> dxf(xf), dg(g), db(b);
+  Dev<uint16_t> dx16(x16), dout((size_t)items * tokens * E);
+  Dev<long long> didx(idx);
+  const void* xp = x_dtype == 0 ? (const void*)dxf.p : (const void*)dx16.p;
+  int rc = launch_modality_ln(xp, x_dtype, didx.p, items, tokens, E, dg.p, db.p, 1e-5f, dout.p, OP_F16, 0);
+  CK(hipDeviceSynchronize());
+  double worst = rc ? 1e30 : 0;
+  std::vector<uint16_t> out = dout.get();
+  for (int it = 0; it < items && !rc; ++it)
+    for (int t = 0; t < tokens; ++t) {
+      const float* xr = xf.data() + ((size_t)idx[it] * tokens + t) * E;
+      double mu = 0, var = 0;
+      for (int i = 0; i < E; ++i) mu += xr[i];
+      mu /= E;
+      for (int i = 0; i < E; ++i) var += (xr[i] - mu) * (xr[i] - mu);
+      var /= E;
+      for (int i = 0; i < E; ++i) {
+        const double ref = (xr[i] - mu) / sqrt(var + 1e-5) * g[i] + b[i];
+        worst = std::max(worst, fabs(ref - from_op(out[((size_t)it * tokens + t) * E + i], OP_F16)) / (1 + fabs(ref)));
+      }
+    }
+  char name[96];
+  snprintf(name, sizeof(name), "modality_ln x_dtype%d E%d gather", x_dtype, E);
+  report(name, worst, 1e-3);
+}
+
+static void test_embed() {
+  const int items = 3, L = 5, Q = 32, H = 768, vocab = 50;
+  std::vector<float> query((size_t)Q * H), word((size_t)vocab * H), pos((size_t)16 * H), g(H), b(H);
+  for (auto& v : query) v = frand(0.02f);
+  for (auto& v : word) v = frand(0.02f);
+  for (auto& v : pos) v = frand(0.02f);
+  for (auto& v : g) v = 1.f + frand(0.1f);
+  for (auto& v : b) v = frand(0.1f);
+  std::vector<long long> ids = {1, 49, 7, 0, 3, 9, 9, 9, 2, 4, 48, 47, 46, 45, 44};
+  Dev<float> dq(query), dw(word), dp(pos), dg(g), db(b), dh((size_t)items * (Q + L) * H);
+  Dev<uint16_t> dh16((size_t)items * (Q + L) * H);
+  Dev<long long> dids(ids);
+  int rc = launch_embed_ln(dids.p, items, L, Q, H, vocab, dq.p, dw.p, dp.p, dg.p, db.p, 1e-12f, dh.p, dh16.p, OP_F16, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> h = dh.get();
+  double worst = rc ? 1e30 : 0;
+  std::vector<double> row(H);
+  for (int n = 0; n < items && !rc; ++n)
+    for (int s = 0; s < Q + L; ++s) {
+      for (int i = 0; i < H; ++i)
+        row[i] = s < Q ? query[(size_t)s * H + i] : (double)word[(size_t)ids[n * L + s - Q] * H + i] + pos[(size_t)(s - Q) * H + i];
+      double mu = 0, var = 0;
+      for (int i = 0; i < H; ++i) mu += row[i];
+      mu /= H;
+      for (int i = 0; i < H; ++i) var += (row[i] - mu) * (row[i] - mu);
+      var /= H;
+      for (int i = 0; i < H; ++i)
+        worst = std::max(worst, fabs((row[i] - mu) / sqrt(var + 1e-12) * g[i] + b[i] - h[((size_t)n * (Q + L) + s) * H + i]));
+    }
+  report("embed_ln", worst, 2e-5);
+}
+
+static void test_score() {
+  const int items = 37, Q = 32, H = 768;
+  std::vector<float> z((size_t)items * Q * H), t((size_t)items * H);
+  for (auto& v : z) v = frand();
+  for (auto& v : t) v = frand();
+  Dev<float> dz(z), dt(t), dsim((size_t)items * Q), dlog(items);
+  int rc = launch_cosine_score(dz.p, dt.p, items, items, Q, H, 1e-8f, dsim.p, dlog.p, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> sim = dsim.get(), lg = dlog.get();
+  double worst = rc ? 1e30 : 0;
+  for (int n = 0; n < items && !rc; ++n) {
+    double best = -1e9;
+    for (int q = 0; q < Q; ++q) {
+      double dot = 0, zz = 0, tt = 0;
+      for (int i = 0; i < H; ++i) {
+        const double a = z[((size_t)n * Q + q) * H + i], b = t[(size_t)n * H + i];
+        dot += a * b; zz += a * a; tt += b * b;
+      }
+      const double s = dot / (sqrt(zz) * sqrt(tt));
+      worst = std::max(worst, fabs(s - sim[(size_t)n * Q + q]));
+      best = std::max(best, s);
+    }
+    worst = std::max(worst, fabs(best - lg[n]));
+  }
+  report("cosine_score", worst, 2e-6);
+  // span: bit-exact integers vs the same two-rounding rule on the host
+  const int videos = 5, clips = 61;
+  std::vector<float> lo((size_t)videos * clips);
+  for (auto& v : lo) v = frand();
+  lo[3] = lo[17] = 9.f;  // tie: first argmax wins
+  Dev<float> dl(lo);
+  Dev<int> dsp(videos * 2);
+  rc = launch_span(dl.p, videos, clips, 0.5f, dsp.p, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<int> sp = dsp.get();
+  int bad = rc ? 1 : 0;
+  for (int v = 0; v < videos && !rc; ++v) {
+    const float* x = lo.data() + (size_t)v * clips;
+    float hi = x[0], mn = x[0];
+    int arg = 0;
+    for (int i = 1; i < clips; ++i) { if (x[i] > hi) { hi = x[i]; arg = i; } mn = std::min(mn, x[i]); }
+    volatile float prod = 0.5f * (hi - mn);
+    volatile float thr = mn + prod;
+    int s = arg, e = arg;
+    while (s - 1 >= 0 && x[s - 1] >= thr) --s;
+    while (e + 1 < clips && x[e + 1] >= thr) ++e;
+    if (sp[2 * v] != s || sp[2 * v + 1] != e) ++bad;
+  }
+  report("span_from_logits (integer mismatches)", bad, 0);
+}
+
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  int dev = 0;
+  CK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, dev));
+  printf("device: %s (%s), %d CUs\n", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+
+  test_ln_rows(OP_F16);
+  test_ln_rows(OP_BF16);
+  test_modality_ln(0, 1408);
+  test_modality_ln(1, 768);
+  test_modality_ln(2, 1408);
+  test_modality_ln(0, 2048);
+  test_embed();
+  test_score();
+
+  // GEMM: every tile config x epilogue, ragged M, row views, grouped
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
+    test_gemm(cfg, EPI_OP, OP_F16, 2 * t + 37, 2 * t, 192, true);
+    test_gemm(cfg, EPI_GELU_OP, OP_F16, t - 5, t, 64, false, 2);
+    test_gemm(cfg, EPI_RES_F32, OP_F16, 3 * t + 1, t, 128, true, 2);
+    test_gemm(cfg, EPI_F32, OP_F16, t, 2 * t, 256, false);
+    test_gemm(cfg, EPI_KV, OP_F16, 2 * t + 10, 2 * t >= 256 ? 2 * t : 256, 128, false);
+    test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
+  }
+  test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+
+  // attention
+  test_attention(OP_F16, 5, 3, 45, 45, true, 1);     // self, ragged masks, 2 query blocks (13 live rows in the 2nd)
+  test_attention(OP_F16, 3, 2, 160, 160, true, 1);   // self, max S
+  test_attention(OP_F16, 3, 2, 32, 100, false, 1);   // cross, short kv: one wave per unit
+  test_attention(OP_F16, 3, 2, 32, 257, false, 1);   // cross, reference shape: 4 waves per unit
+  test_attention(OP_F16, 2, 2, 32, 2100, false, 3);  // cross, grid split + combine
+  test_attention(OP_F16, 2, 2, 32, 2100, false, 1, true);  // rescale path forced
+  test_attention(OP_BF16, 2, 2, 32, 257, false, 1);
+  test_attention(OP_BF16, 2, 2, 64, 64, true, 1);
+  if (!quick) {
+    test_attention(OP_F16, 2, 12, 32, 8224, false, 4);
+    test_gemm(2, EPI_KV, OP_F16, 2100, 1536, 1408, false);
+  }
+  printf("%d case(s) failed\n", g_fail);
+  return g_fail;
+}
