@@ -1,0 +1,209 @@
+"""bench.py -- clips/s of the encode/fuse/score hot path on 1..8 MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input that is already resident in
+HBM: per GPU 32 clips, each clip = 32 video frames (32 x 257 = 8224 ViT-g tokens x 1408, the
+BASELINE "32-clip x 32-frame" shape) + 10 s of audio (496 BEATs tokens x 768), a
+32-token prompt.  Timed: modality LayerNorm -> video Q-Former -> audio Q-Former -> (N > 1: RCCL
+all-gather of the query embeddings) -> cosine scores -> fusion -> integer spans.  Nothing is skipped
+or cached between steps.  The ViT-g / BEATs encoders (stock PyTorch, not part of this build's
+kernels) are NOT in the timed region: the features are the synthetic input (BASELINE configs 1-4).
+Weak scaling: every GPU holds its own 32 clips of a 32*N-clip video; value = all clips / time.
+
+Also on the JSON line: `roofline` of the dominant kernel (the K/V projection GEMM, timed alone with
+events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU
+    box hands one GPU's share of a large host; os.cpu_count() would oversubscribe it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="clip32x32", choices=["clip32x32", "ref"],
+                    help="clip32x32: Kv=8224 video / 496 audio tokens per clip (headline); ref: the reference's one-frame items (257 / 256)")
+    ap.add_argument("--clips", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--text-len", type=int, default=32)
+    ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mraudio_amd import _lib
+    from mraudio_amd.models.xinstructblip import ENC_WIDTH, XInstructBLIP
+
+    kv = {"video": 32 * 257, "audio": 496} if args.workload == "clip32x32" else {"video": 257, "audio": 256}
+    n_local, L = args.clips, args.text_len
+    n_total = n_local * world
+    op_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
+    model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    feats = {m: torch.randn(n_local, kv[m], ENC_WIDTH[m], generator=g, device=dev, dtype=torch.float16) for m in ("video", "audio")}
+    ids = torch.randint(1000, 30000, (n_local, L), generator=g, device=dev)
+    tmask = torch.ones(n_local, L, dtype=torch.long, device=dev)
+
+    def step():
+        # one video of n_total clips (bs = 1); this rank owns clips [rank*n_local, (rank+1)*n_local)
+        return model.fuse_score(feats, ids, tmask, bs=1, num=n_total)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: model ready, {n_local} clips/GPU, kv {kv}")
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    log("warm-up done")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out["fused"]).all()
+    value = n_total * args.steps / dt
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
+
+    # ---- roofline of the dominant kernel: the K/V projection GEMM of the video Q-Former ----
+    qf = model.video_Qformer
+    lib = _lib.lib()
+    enc = qf.modality_ln(feats["video"])
+    nb = int(lib.mra_kv_cache_bytes(qf._handle, n_local, kv["video"]))
+    cache = torch.empty(nb, dtype=torch.uint8, device=dev)
+    reps = 5
+    for _ in range(2):
+        _lib.check(lib.mra_kv_project(qf._handle, _lib.ptr(enc), n_local, kv["video"], _lib.ptr(cache), _lib.current_stream()), "kv_project")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()  # torch's current stream == the stream the launches go to
+    for _ in range(reps):
+        _lib.check(lib.mra_kv_project(qf._handle, _lib.ptr(enc), n_local, kv["video"], _lib.ptr(cache), _lib.current_stream()), "kv_project")
+    e1.record()
+    torch.cuda.synchronize()
+    kv_ms = e0.elapsed_time(e1) / reps
+    ncross, H, E = 6, 768, ENC_WIDTH["video"]
+    kv_flops = 2.0 * n_local * kv["video"] * E * (ncross * 2 * H)
+    achieved = kv_flops / (kv_ms * 1e-3) / 1e12
+    del cache, enc
+
+    flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
+
+    # ---- CPU baseline: the oracle (a CPU port of the same path) on a bounded sample ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_clips != 0:
+        cpu = cpu_baseline(args, kv, L)
+
+    if rank == 0:
+        line = {
+            "metric": "clips/s encode+fuse+score, 32-clip x 32-frame synthetic",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": ("32 clips/GPU x 32 frames: video Kv=8224 x1408 + 10 s audio Kv=496 x768, L=32; "
+                             "features resident in HBM (f16); LN + Q-Former(video) + Q-Former(audio) + cosine score + span"
+                             if args.workload == "clip32x32" else
+                             "32 items/GPU, reference item shape: video Kv=257 x1408 + audio Kv=256 x768, L=32; LN + 2 Q-Formers + score + span"),
+                "clips_per_gpu": n_local, "global_clips": n_total, "text_len": L, "kv_video": kv["video"], "kv_audio": kv["audio"],
+                "parallelism": f"clip-shard x{world}" + (" + RCCL all-gather of query embeddings" if world > 1 else ""),
+                "encoders": "not timed (synthetic features stand in for ViT-g / BEATs outputs)",
+                "weights": "synthetic BERT init, seed 0",
+            },
+            "tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<256x256, EPI_KV> (K/V projection of all cross layers)",
+                         "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, kv, L):
+    """The oracle (kind "port": a CPU restatement in torch fp32, all host threads) on the same
+    workload, bounded to a few clips so the default run stays within minutes."""
+    from mraudio_amd.models.xinstructblip import ENC_WIDTH
+    from oracle import qformer_ref as O
+
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    log(f"cpu baseline: {threads} threads")
+    n = args.cpu_clips if args.cpu_clips > 0 else (4 if args.workload == "clip32x32" else 32)
+    cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
+    ws = {"video": O.init_weights(cfgs["video"], seed=0), "audio": O.init_weights(cfgs["audio"], seed=1)}
+    g = torch.Generator().manual_seed(1234)
+    feats = {m: torch.randn(n, kv[m], ENC_WIDTH[m], generator=g) for m in ("audio", "video")}
+    ids = torch.randint(1000, 30000, (n, L), generator=g)
+    tm = torch.ones(n, L, dtype=torch.long)
+    with torch.no_grad():
+        O.encode_fuse_score(ws, cfgs, {m: feats[m][:1] for m in feats}, ids[:1], tm[:1], 1, 1)  # warm-up
+        t0 = time.perf_counter()
+        O.encode_fuse_score(ws, cfgs, feats, ids, tm, 1, n)
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{n} clips of the same workload, one pass after a 1-clip warm-up, torch fp32 oracle, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,8 @@ int mra_modality_ln(mra_qformer* h, const void* x, int32_t x_dtype, const int64_
  * all ones in the reference and is not an input here.
  *   input_ids      [items, L] int64
  *   attention_mask [items, n_query + L] int64 (1 = attend) or NULL = all ones
+ *   query_embeds   [query_items, n_query, hidden] f32 with query_items == 1 (broadcast) or == items,
+ *                  or NULL = the loaded "query_tokens" parameter
  *   enc            [items, kv, enc_width] operand dtype (output of mra_modality_ln)
  *   out_query      [items, n_query, hidden] f32 = last_hidden_state[:, :32, :]        (required)
  *   out_full       [items, n_query + L, hidden] f32 = last_hidden_state, or NULL
@@ -109,9 +111,17 @@ int mra_modality_ln(mra_qformer* h, const void* x, int32_t x_dtype, const int64_
  * When neither out_full nor out_cls is given the last layer's text feed-forward is skipped
  * (its result is never read by the reference either: only [:, :32] is sliced, :303). */
 size_t mra_qformer_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv);
-int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
-                        int32_t items, int32_t L, int32_t kv, float* out_query, float* out_full, float* out_cls,
-                        void* workspace, size_t workspace_bytes, void* stream);
+int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask,
+                        const float* query_embeds, int32_t query_items, const void* enc, int32_t items, int32_t L,
+                        int32_t kv, float* out_query, float* out_full, float* out_cls, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* The dominant launch of the forward on its own (what bench.py prices against the MFMA roofline):
+ * K and V of every cross-attention layer, enc [items*kv, enc_width] x Wkv[n_cross*2*hidden, enc_width]^T
+ * + bias, written head-major into kv_cache [n_cross][2][items][heads][kv][64] (operand dtype,
+ * mra_kv_cache_bytes).  mra_qformer_forward performs exactly this launch as its second step. */
+size_t mra_kv_cache_bytes(mra_qformer* h, int32_t items, int32_t kv);
+int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, void* kv_cache, void* stream);
 
 /* ---- A5: LLM projection ---------------------------------------------------------------------------
  * replaces: {modality}_llm_proj(last_hidden_state[:, :32, :]) (models/xinstructblip.py:303).

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libmra_hip.so`` (the C ABI declared in ``include/mra.h``).
+
+There is no CPU fallback: if the library is missing this raises, and every op in
+``mraudio_amd`` goes through it.  ``torch`` is imported first on purpose: the PyTorch-ROCm wheel
+ships its own ``libamdhip64.so.7`` and the HIP runtime must be shared with it so that the device
+pointers and streams torch hands us are valid inside the kernels' launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the extension binds to)
+
+MRA_F32, MRA_F16, MRA_BF16 = 0, 1, 2
+_ERR = {-1: "MRA_EINVAL", -2: "MRA_ESTATE", -3: "MRA_EHIP", -4: "MRA_ENOMEM", -5: "MRA_ENAME"}
+
+LIB_NAME = "libmra_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class mra_cfg(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("heads", C.c_int32), ("inter", C.c_int32), ("layers", C.c_int32),
+        ("cross_freq", C.c_int32), ("enc_width", C.c_int32), ("n_query", C.c_int32), ("vocab", C.c_int32),
+        ("max_pos", C.c_int32), ("ln_eps", C.c_float), ("enc_ln_eps", C.c_float), ("llm_hidden", C.c_int32),
+        ("op_dtype", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/mra.h declares (tests check this)
+PROTOTYPES = {
+    "mra_cfg_default": (None, [C.POINTER(mra_cfg), C.c_int32]),
+    "mra_last_error": (C.c_char_p, []),
+    "mra_version": (C.c_char_p, []),
+    "mra_qformer_create": (C.c_int, [C.POINTER(mra_cfg), C.POINTER(C.c_void_p)]),
+    "mra_qformer_destroy": (None, [C.c_void_p]),
+    "mra_qformer_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int32,
+                                   C.c_void_p]),
+    "mra_qformer_missing": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "mra_modality_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p]),
+    "mra_qformer_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "mra_qformer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
+    "mra_kv_cache_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mra_kv_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mra_llm_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                               C.c_void_p]),
+    "mra_cosine_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "mra_fuse_logits": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p]),
+    "mra_span_from_logits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "mra_qformer_flops": (C.c_double, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+}
+
+_lib = None
+
+
+class MraError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """The loaded extension; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MraError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C mraudio_amd/csrc). "
+                "mraudio_amd has no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mra_last_error().decode("utf-8", "replace")
+        raise MraError(f"{what}: {_ERR.get(rc, rc)}: {msg}")
+
+
+def ptr(t) -> C.c_void_p:
+    """Device (or host) address of a tensor, None -> NULL."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def current_stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def mra_dtype(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MRA_F32
+    if dt == torch.float16:
+        return MRA_F16
+    if dt == torch.bfloat16:
+        return MRA_BF16
+    raise MraError(f"unsupported dtype {dt}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return {MRA_F32: torch.float32, MRA_F16: torch.float16, MRA_BF16: torch.bfloat16}[code]

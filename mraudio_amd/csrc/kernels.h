@@ -86,7 +86,9 @@ int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gai
 int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, int items, int tokens, int E,
                        const float* gain, const float* bias, float eps, void* out, int op_dtype, hipStream_t stream);
 // Embeddings (A4a): h[n, s] = LN(s < Q ? query[s] : word[ids[n, s-Q]] + pos[s-Q])
-int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query, const float* word,
+// query: [1 or items][Q][H]; query_item_stride = 0 broadcasts one set of query tokens to every item
+int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query,
+                    long long query_item_stride, const float* word,
                     const float* pos, const float* gain, const float* bias, float eps, float* h32, void* h16,
                     int op_dtype, hipStream_t stream);
 // dst(op dtype)[rows][cols] at row offset <- src (0 = f32, 1 = f16, 2 = bf16)

@@ -240,6 +240,25 @@ int chk(int rc, const char* what) {
   return fail(rc == -1 ? MRA_EINVAL : MRA_EHIP, std::string(what) + " failed (rc " + std::to_string(rc) + ")");
 }
 
+// K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
+int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream) {
+  const mra_cfg& c = h->cfg;
+  GemmProb p{};
+  p.A = enc;
+  p.a = plain(N * kv, c.enc_width);
+  p.W = h->wkv;
+  p.bias = h->bkv;
+  p.C = kv_cache;
+  p.c = plain(1, 1);
+  p.M = N * kv;
+  p.N = h->ncross * 2 * c.hidden;
+  p.K = c.enc_width;
+  p.kv_tokens = kv;
+  p.kv_items = N;
+  p.kv_heads = c.heads;
+  return launch_gemm(&p, 1, EPI_KV, h->op(), stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -357,9 +376,10 @@ double mra_qformer_flops(mra_qformer* h, int32_t items, int32_t L, int32_t kv, i
   return per_item * items;
 }
 
-int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
-                        int32_t items, int32_t L, int32_t kv, float* out_query, float* out_full, float* out_cls,
-                        void* workspace, size_t workspace_bytes, void* stream_) {
+int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask,
+                        const float* query_embeds, int32_t query_items, const void* enc, int32_t items, int32_t L,
+                        int32_t kv, float* out_query, float* out_full, float* out_cls, void* workspace,
+                        size_t workspace_bytes, void* stream_) {
   if (!h) return fail(MRA_EINVAL, "null handle");
   if (items < 0 || L < 0 || kv < 0) return fail(MRA_EINVAL, "negative size");
   if (items == 0) return MRA_OK;
@@ -368,6 +388,8 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
   if (L > c.max_pos) return fail(MRA_EINVAL, "L exceeds max_pos");
   if (!enc || (L > 0 && !input_ids)) return fail(MRA_EINVAL, "null input");
   if (out_cls && L < 1) return fail(MRA_EINVAL, "out_cls needs L >= 1");
+  if (query_embeds && query_items != 1 && query_items != items)
+    return fail(MRA_EINVAL, "query_items must be 1 or items");
   if (!out_query && !out_full && !out_cls) return fail(MRA_EINVAL, "no output requested");
   {
     char names[256];
@@ -400,26 +422,15 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
   const RowView qc_rows = plain(N * Q, H);              // compact [N*32, H]
 
   // embeddings
-  int rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, c.vocab, h->query, h->word, h->pos, h->embg, h->embb,
-                           c.ln_eps, w.hA32, w.hA16, op, stream);
+  const float* qsrc = query_embeds ? query_embeds : h->query;
+  const long long qstride = query_embeds && query_items == items && items > 1 ? (long long)Q * H : 0;
+  int rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, c.vocab, qsrc, qstride, h->word, h->pos, h->embg,
+                           h->embb, c.ln_eps, w.hA32, w.hA16, op, stream);
   if (rc) return chk(rc, "embed_ln");
 
   // K/V of every cross layer in one GEMM, scattered head-major
   if (h->ncross > 0) {
-    GemmProb p{};
-    p.A = enc;
-    p.a = plain(N * kv, E);
-    p.W = h->wkv;
-    p.bias = h->bkv;
-    p.C = w.kv16;
-    p.c = plain(1, 1);
-    p.M = N * kv;
-    p.N = h->ncross * 2 * H;
-    p.K = E;
-    p.kv_tokens = kv;
-    p.kv_items = N;
-    p.kv_heads = c.heads;
-    rc = launch_gemm(&p, 1, EPI_KV, op, stream);
+    rc = kv_project(h, enc, N, kv, w.kv16, stream);
     if (rc) return chk(rc, "kv projection gemm");
   }
 
@@ -593,6 +604,20 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
     }
   }
   return MRA_OK;
+}
+
+size_t mra_kv_cache_bytes(mra_qformer* h, int32_t items, int32_t kv) {
+  if (!h || items <= 0 || kv <= 0) return 0;
+  return (size_t)h->ncross * 2 * items * kv * h->cfg.hidden * 2;
+}
+
+int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, void* kv_cache, void* stream) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (items < 0 || kv < 0) return fail(MRA_EINVAL, "negative size");
+  if (items == 0 || kv == 0 || h->ncross == 0) return MRA_OK;
+  if (!enc || !kv_cache) return fail(MRA_EINVAL, "null argument");
+  if ((long long)items * kv > 0x7fffffffLL) return fail(MRA_EINVAL, "items * kv exceeds int32");
+  return chk(kv_project(h, enc, items, kv, kv_cache, as_stream(stream)), "kv projection gemm");
 }
 
 int mra_llm_proj(mra_qformer* h, const float* z, int32_t rows, void* out, int32_t out_dtype, void* workspace,

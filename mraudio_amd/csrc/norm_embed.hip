@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) modality_ln_kernel(const TI* x, const lon
 
 template <typename T, int NV>
 __global__ void __launch_bounds__(256) embed_ln_kernel(const long long* ids, int items, int L, int Q, int vocab,
-                                                       const float* query, const float* word, const float* pos,
+                                                       const float* query, long long qstride, const float* word, const float* pos,
                                                        const float* gain, const float* bias, float eps, float* h32,
                                                        T* h16) {
   constexpr int H = NV * 256;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const long long* ids, int
   float sum = 0.f;
   if (s < Q) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(query + (long long)s * H + (i * 64 + lane) * 4);
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(query + item * qstride + (long long)s * H + (i * 64 + lane) * 4);
   } else {
     long long id = ids[(long long)item * L + (s - Q)];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never fault on a bad token id
@@ -281,14 +281,14 @@ int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, 
 }
 
 int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query,
-                    const float* word, const float* pos, const float* gain, const float* bias, float eps, float* h32,
+                    long long query_item_stride, const float* word, const float* pos, const float* gain, const float* bias, float eps, float* h32,
                     void* h16, int op_dtype, hipStream_t stream) {
   if (items <= 0) return 0;
   if (H % 256 || H > 1024 || H <= 0 || L < 0 || Q < 0) return -1;
   const long long rows = (long long)items * (Q + L);
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define MRA_EM_CASE(T, NV)                                                                                        \
-  hipLaunchKernelGGL((embed_ln_kernel<T, NV>), grid, block, 0, stream, ids, items, L, Q, vocab, query, word, pos, \
+  hipLaunchKernelGGL((embed_ln_kernel<T, NV>), grid, block, 0, stream, ids, items, L, Q, vocab, query, query_item_stride, word, pos, \
                      gain, bias, eps, h32, (T*)h16)
   const int nv = H / 256;
   if (op_dtype == OP_F16) {

@@ -63,7 +63,13 @@ __global__ void __launch_bounds__(256) fuse_kernel(FuseArgs a, int n, float* out
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float acc = 0.f;
-  for (int m = 0; m < a.nmod; ++m) acc = __fadd_rn(acc, __fmul_rn(a.x[m][i], a.w[m]));  // no fma contraction
+  {
+#pragma clang fp contract(off)  // the oracle rounds the product and the sum separately: no fma here
+    for (int m = 0; m < a.nmod; ++m) {
+      const float prod = a.x[m][i] * a.w[m];
+      acc = acc + prod;
+    }
+  }
   out[i] = acc;
 }
 
@@ -91,9 +97,9 @@ __global__ void __launch_bounds__(64) span_kernel(const float* logits, int clips
     const float range = hi - lo;
     float thr;
     {
-      // keep the multiply and the add as two separately rounded operations
-      const float prod = __fmul_rn(alpha, range);
-      thr = __fadd_rn(lo, prod);
+#pragma clang fp contract(off)  // multiply and add rounded separately, as the oracle does
+      const float prod = alpha * range;
+      thr = lo + prod;
     }
     int s = arg, e = arg;
     while (s - 1 >= 0 && x[s - 1] >= thr) --s;

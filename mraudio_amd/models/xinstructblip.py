@@ -1,0 +1,389 @@
+"""``XInstructBLIP`` with the reference's Python surface, its encode/fuse hot path on MI355X kernels.
+
+Mirrors ``models/xinstructblip.py`` of the reference (class at ``:51``):
+
+* ``XInstructBLIP(model_path, audio_path)``; attributes ``{m}_encoder``, ``{m}_ln``, ``{m}_Qformer``,
+  ``{m}_query_tokens``, ``{m}_llm_proj`` with the checkpoint key names the reference's loader routes
+  (``:769-816``); ``.generate(samples) -> list[str]`` (``:222``), ``.forward(samples) -> {"loss"}``
+  (``:399``), ``.load_state_dict`` returning ``_IncompatibleKeys``, ``.get_optimizer_params``.
+* ``samples`` schema as produced by ``utils/mr_dataset.py`` + ``collate_fn``:
+  ``video [B,3,T,224,224]``, ``audio [B,T,F,128]``, ``text_input``, ``timestamps``, ``duration``.
+
+What differs, on purpose: the reference hands the projected query embeddings to an
+8-bit Vicuna-7B and parses generated text; here ``generate`` scores clips with the cosine scorer and
+formats the span as the same ``"[[start, end]]"`` string, so ``evaluate.py``-shaped callers
+(``moment_str_to_list(post_process(out))``, ``evaluate.py:48``) run unchanged.  The ViT-g / BEATs
+encoders (row A1) are pluggable stock PyTorch modules; pre-computed encoder outputs can be passed
+as ``samples["video_embeds"] [B,T,Kv,1408]`` / ``samples["audio_embeds"] [B,T,Kv,768]``.
+
+All arithmetic between the encoder output and the span runs in ``libmra_hip.so``: modality
+LayerNorm + reorder (``:265,281-285``), Q-Former (``:286-293``), slice + llm_proj (``:303-306``),
+scorer.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import logging
+import re
+import zlib
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.module import _IncompatibleKeys
+
+from .. import parallel, scorer
+from .._lib import MraError
+from ..qformer import QFormer, QFormerConfig, draw_seeded
+
+
+class HashTokenizer:
+    """Offline stand-in for ``BertTokenizer("bert-base-uncased")`` (reference ``:609-612``), whose
+    vocabulary file is a network download.  Lower-cased words and punctuation map to stable ids in
+    [1000, 30521] by CRC32; [CLS]=101, [SEP]=102, [PAD]=0; same call signature and outputs
+    (``input_ids``, ``attention_mask``, right padding to the longest, left truncation).
+    Token ids are synthetic: use the real tokenizer with real checkpoints."""
+
+    cls_id, sep_id, pad_id = 101, 102, 0
+
+    def __init__(self, truncation_side: str = "left"):
+        self.truncation_side = truncation_side
+
+    def __len__(self):
+        return 30523
+
+    def _encode(self, text: str, max_length: int) -> List[int]:
+        words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", text.lower())
+        ids = [1000 + zlib.crc32(w.encode()) % 29522 for w in words]
+        room = max_length - 2
+        if len(ids) > room:
+            ids = ids[-room:] if self.truncation_side == "left" else ids[:room]
+        return [self.cls_id] + ids + [self.sep_id]
+
+    def __call__(self, text, padding="longest", truncation=True, max_length=128, return_tensors="pt", **unused):
+        texts = [text] if isinstance(text, str) else list(text)
+        enc = [self._encode(t, max_length) for t in texts]
+        width = max(len(e) for e in enc)
+        ids = torch.full((len(enc), width), self.pad_id, dtype=torch.long)
+        att = torch.zeros((len(enc), width), dtype=torch.long)
+        for i, e in enumerate(enc):
+            ids[i, : len(e)] = torch.tensor(e)
+            att[i, : len(e)] = 1
+        return _Encoding(ids, att)
+
+
+class _Encoding:
+    def __init__(self, input_ids, attention_mask):
+        self.input_ids, self.attention_mask = input_ids, attention_mask
+
+    def to(self, device):
+        return _Encoding(self.input_ids.to(device), self.attention_mask.to(device))
+
+
+class LayerNorm(nn.Module):
+    """``{modality}_ln`` (reference ``:822-828``): fp32 LayerNorm, eps 1e-5, result in the input dtype.
+    Parameter container; called directly it runs the HIP modality-LN kernel and returns the operand
+    dtype tensor the Q-Former consumes."""
+
+    def __init__(self, num_features: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_features), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(num_features), requires_grad=False)
+        object.__setattr__(self, "_qformer_ref", None)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        qf = self._qformer_ref()
+        shape = x.shape
+        return qf.modality_ln(x.reshape(-1, shape[-2], shape[-1])).reshape(shape)
+
+
+class _Proj(nn.Module):
+    def __init__(self, in_f: int, out_f: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_f), requires_grad=False)
+        object.__setattr__(self, "_qformer_ref", None)
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        return self._qformer_ref().llm_proj(z)
+
+
+ENC_WIDTH = {"video": 1408, "audio": 768}  # EVA ViT-g / BEATs num_features (reference :123)
+
+
+class XInstructBLIP(nn.Module):
+    def __init__(self, model_path: Optional[str] = None, audio_path: Optional[str] = None, *,
+                 modalities: Optional[Sequence[str]] = None, video_encoder: Optional[nn.Module] = None,
+                 audio_encoder: Optional[nn.Module] = None, tokenizer=None, seed: Optional[int] = 0,
+                 perturb: bool = False, op_dtype: torch.dtype = torch.float16, device=None,
+                 compat_repeat: bool = True, score_alpha: float = 0.5, fuse_weights: Optional[Sequence[float]] = None,
+                 process_group=None, qformer_overrides: Optional[dict] = None):
+        super().__init__()
+        self.model_path, self.audio_path = model_path, audio_path
+        self.modalities = list(modalities) if modalities is not None else ["audio", "video"]  # reference :71
+        self.max_txt_len = 128           # reference :75
+        self.max_output_txt_len = 64
+        self.num_query_token = 32        # reference :120
+        self.compat_repeat = compat_repeat
+        self.score_alpha = score_alpha
+        self.fuse_weights = fuse_weights
+        self.process_group = process_group
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.tokenizer = tokenizer if tokenizer is not None else self.init_tokenizer(truncation_side="left")
+        self.video_encoder = video_encoder
+        self.audio_encoder = audio_encoder
+        self.llm_hidden_size = 4096
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        # synthetic init draws modalities in sorted order so the tensors do not depend on list order
+        for m in sorted(self.modalities):
+            cfg = QFormerConfig(enc_width=ENC_WIDTH[m], op_dtype=op_dtype, llm_hidden=self.llm_hidden_size,
+                                **(qformer_overrides or {}))
+            qf, qt = self.init_Qformer(self.num_query_token, ENC_WIDTH[m], cfg=cfg, device=self._device)
+            setattr(self, f"{m}_Qformer", qf)
+            setattr(self, f"{m}_query_tokens", qt)
+            ln = self.init_ln(ENC_WIDTH[m])
+            proj = self.init_vicuna_projection(cfg.hidden, self.llm_hidden_size)
+            setattr(self, f"{m}_ln", ln)
+            setattr(self, f"{m}_llm_proj", proj)
+            object.__setattr__(ln, "_qformer_ref", _ref(qf))
+            object.__setattr__(proj, "_qformer_ref", _ref(qf))
+            if gen is not None:
+                mg = torch.Generator().manual_seed(int(seed) + (0 if m == "video" else 1))
+                qf.init_seeded_(perturb=perturb, gen=mg)
+                qt.data.copy_(draw_seeded(mg, (1, cfg.n_query, cfg.hidden), "w", perturb))
+                ln.weight.data.copy_(draw_seeded(mg, (cfg.enc_width,), "g", perturb))
+                ln.bias.data.copy_(draw_seeded(mg, (cfg.enc_width,), "z", perturb))
+                proj.weight.data.copy_(draw_seeded(mg, (self.llm_hidden_size, cfg.hidden), "w", perturb))
+                proj.bias.data.copy_(draw_seeded(mg, (self.llm_hidden_size,), "b", perturb))
+        self.to(self._device)
+        self._extras_dirty = True
+
+    # ---- construction helpers with the reference's names (:609-735) --------------------------------
+    @classmethod
+    def init_tokenizer(cls, truncation_side="right"):
+        try:  # the real vocabulary when it is on disk; never a download
+            from transformers import BertTokenizer
+            tok = BertTokenizer.from_pretrained("bert-base-uncased", truncation_side=truncation_side, local_files_only=True)
+            tok.add_special_tokens({"bos_token": "[DEC]"})
+            return tok
+        except Exception:
+            logging.info("bert-base-uncased vocabulary not on disk: using the offline HashTokenizer")
+            return HashTokenizer(truncation_side=truncation_side)
+
+    @classmethod
+    def init_Qformer(cls, num_query_token, modality_width, cross_attention_freq=2, cfg: Optional[QFormerConfig] = None,
+                     device=None):
+        cfg = cfg or QFormerConfig(enc_width=modality_width, cross_freq=cross_attention_freq, n_query=num_query_token)
+        qformer = QFormer(cfg, device=device)
+        query_tokens = nn.Parameter(torch.zeros(1, num_query_token, cfg.hidden), requires_grad=False)
+        return qformer, query_tokens
+
+    @classmethod
+    def init_ln(cls, num_features, load_ln_path=False, load_ln_type=""):
+        return LayerNorm(num_features)
+
+    @classmethod
+    def init_vicuna_projection(cls, input_size, output_size, load_projection_path=False, load_projection_type="", projection_key=None):
+        return _Proj(input_size, output_size)
+
+    @property
+    def device(self):
+        return self._device
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._extras_dirty = True
+        return out
+
+    # ---- checkpoints (reference :737-816) --------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Routes ``{m}_Qformer.*``, ``{m}_query_tokens``, ``{m}_ln.*``, ``{m}_llm_proj.*`` as the
+        reference does (``:769-816``); ``llm_model.*`` and encoder keys are ignored here (no LLM on
+        this path)."""
+        missing, unexpected = [], []
+        for m in self.modalities:
+            sub = {".".join(k.split(".")[1:]): v for k, v in state_dict.items() if k.split(".")[0] == f"{m}_Qformer"}
+            msg = getattr(self, f"{m}_Qformer").load_state_dict(sub, strict=False)
+            missing += [f"{m}_Qformer.{k}" for k in msg.missing_keys]
+            unexpected += [f"{m}_Qformer.{k}" for k in msg.unexpected_keys]
+            if f"{m}_query_tokens" not in state_dict:
+                missing.append(f"{m}_query_tokens")
+            else:
+                getattr(self, f"{m}_query_tokens").data.copy_(state_dict[f"{m}_query_tokens"])
+            for part in ("ln", "llm_proj"):
+                sub = {".".join(k.split(".")[1:]): v for k, v in state_dict.items() if k.split(".")[0] == f"{m}_{part}"}
+                msg = nn.Module.load_state_dict(getattr(self, f"{m}_{part}"), sub, strict=False)
+                missing += [f"{m}_{part}.{k}" for k in msg.missing_keys]
+                unexpected += [f"{m}_{part}.{k}" for k in msg.unexpected_keys]
+        known = tuple(f"{m}_" for m in self.modalities)
+        unexpected += [k for k in state_dict if not k.startswith(known) and k.split(".")[0] != "llm_model"
+                       and "encoder" not in k.split(".")[0]]
+        self._extras_dirty = True
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for XInstructBLIP: missing {missing}, unexpected {unexpected}")
+        return _IncompatibleKeys(missing, unexpected)
+
+    def load_checkpoint(self, filename, **kwargs):
+        ckpt = torch.load(filename, map_location="cpu", weights_only=True)
+        return self.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=True)
+
+    def get_optimizer_params(self, weight_decay, lr_scale=1):
+        """LAVIS ``BaseModel.get_optimizer_params`` semantics (reference ``:818-820``): parameters that
+        require grad, split into decay / no-decay (ndim < 2, bias, ln, bn) groups."""
+        decay, no_decay = [], []
+        for n, p in self.named_parameters():
+            if not p.requires_grad:
+                continue
+            (no_decay if p.ndim < 2 or "bias" in n or "ln" in n or "bn" in n else decay).append(p)
+        return [{"params": decay, "weight_decay": weight_decay, "lr_scale": lr_scale},
+                {"params": no_decay, "weight_decay": 0, "lr_scale": lr_scale}]
+
+    def _sync(self):
+        for m in self.modalities:
+            qf: QFormer = getattr(self, f"{m}_Qformer")
+            qf.sync_weights()
+            if self._extras_dirty:
+                qf.push("query_tokens", getattr(self, f"{m}_query_tokens"))
+                qf.push("ln.weight", getattr(self, f"{m}_ln").weight)
+                qf.push("ln.bias", getattr(self, f"{m}_ln").bias)
+                qf.push("llm_proj.weight", getattr(self, f"{m}_llm_proj").weight)
+                qf.push("llm_proj.bias", getattr(self, f"{m}_llm_proj").bias)
+        self._extras_dirty = False
+
+    # ---- the hot path -------------------------------------------------------------------------------------
+    def _encode(self, samples, modality: str):
+        """Row A1: per-position encoder calls (reference ``:262-275``).  Returns
+        (raw [src_items, Kv, E] encoder outputs, index or None, bs, num): item k of the sample-major
+        order the reference builds with ``cat(embeds)[indices]`` (``:281-285``) is ``raw[index[k]]``."""
+        key = f"{modality}_embeds"
+        if key in samples:  # pre-computed encoder outputs, already sample-major [B, T, Kv, E]
+            e = samples[key].to(self._device)
+            bs, num = int(e.shape[0]), int(e.shape[1])
+            return e.reshape(bs * num, e.shape[2], e.shape[3]), None, bs, num
+        encoder = getattr(self, f"{modality}_encoder")
+        if encoder is None:
+            raise MraError(f"no {modality}_encoder was given and samples has no '{key}'")
+        data = samples[modality].to(self._device)
+        frames = []
+        with torch.no_grad():
+            if modality == "video":
+                for j in range(data.size(2)):
+                    frames.append(encoder(data[:, :, j, :, :]))
+            else:
+                for j in range(data.size(1)):
+                    frames.append(encoder(data[:, j, :, :]))
+        num, bs = len(frames), int(frames[0].shape[0])
+        raw = torch.cat(frames)  # frame-major [num*bs, Kv, E]
+        index = torch.tensor([i * bs + r for r in range(bs) for i in range(num)], dtype=torch.int64, device=raw.device)
+        return raw, index, bs, num
+
+    @torch.no_grad()
+    def fuse_score(self, embeds: Dict[str, torch.Tensor], input_ids: torch.Tensor, text_mask: torch.Tensor, bs: int, num: int,
+                   index: Optional[Dict[str, torch.Tensor]] = None, want_llm: bool = False, want_full: bool = False) -> Dict[str, object]:
+        """Everything after the encoders and the tokenizer, on THIS rank's block of items.
+
+        ``embeds[m]`` raw encoder outputs; the rank's items are ``embeds[m][index[m]]`` when an index is
+        given, else ``embeds[m]`` itself (``[n_local, Kv, E]``).  ``input_ids`` / ``text_mask``
+        ``[n_local, L]``.  The rank's block is rows ``shard_range(bs*num, rank, world)`` of the
+        sample-major item order.  LN + reorder -> Q-Former -> all-gather of the query embeddings and
+        [CLS] vectors over the process group -> cosine score -> fuse -> span (identical on all ranks)."""
+        self._sync()
+        n = bs * num
+        rank, ws = parallel.world(self.process_group)
+        lo, hi = parallel.shard_range(n, rank, ws)
+        n_local = hi - lo
+        out: Dict[str, object] = {"z": {}, "cls": {}, "sim": {}, "logit": {}, "full": {}}
+        ids = input_ids.to(self._device)
+        tmask = text_mask.to(self._device)
+        att = torch.cat([torch.ones(n_local, self.num_query_token, dtype=torch.long, device=self._device), tmask], dim=1)
+        for m in self.modalities:
+            if m not in embeds:
+                continue
+            qf: QFormer = getattr(self, f"{m}_Qformer")
+            idx = None if index is None else index.get(m)
+            enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
+            res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True)
+            z = parallel.all_gather_rows(res["query"], n, self.process_group)
+            cls = parallel.all_gather_rows(res["cls"], n, self.process_group)
+            sim, logit = scorer.cosine_scores(z, cls)
+            out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
+            if want_full:
+                out["full"][m] = parallel.all_gather_rows(res["full"], n, self.process_group)
+            if want_llm:  # reference :303-306
+                y = qf.llm_proj(z)
+                out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
+                out.setdefault("atts_llm", {})[m] = torch.ones(bs, num * self.num_query_token, dtype=torch.long, device=self._device)
+        mods = [m for m in self.modalities if m in out["logit"]]
+        if not mods:
+            raise MraError("no features for any of the model's modalities")
+        out["fused"] = scorer.fuse_logits([out["logit"][m] for m in mods], self.fuse_weights)
+        out["spans"] = scorer.spans_from_logits(out["fused"], bs, num, self.score_alpha)
+        out["bs"], out["num"] = bs, num
+        return out
+
+    @torch.no_grad()
+    def encode_fuse(self, samples, want_llm: bool = False, want_full: bool = False) -> Dict[str, object]:
+        """The seam ``generate`` and ``forward`` share (reference ``:228-306`` / ``:409-478``).
+
+        Returns ``z[m]`` [N,32,768] (= ``last_hidden_state[:, :32]``), ``cls[m]`` [N,768], ``sim[m]``
+        [N,32], ``logit[m]`` [N], ``fused`` [N], ``spans`` int32 [B,2]; with ``want_llm`` also
+        ``inputs_llm[m]`` [B, T*32, 4096] and ``atts_llm[m]`` (``:303-306``).  With a process group the
+        items are sharded in contiguous blocks over the ranks (every rank is given the same samples)."""
+        prompt = samples["text_input"]
+        text = self.tokenizer(prompt, padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
+        ids, tmask = text.input_ids.to(self._device), text.attention_mask.to(self._device)
+        rank, ws = parallel.world(self.process_group)
+        embeds, index = {}, {}
+        bs = num = None
+        for m in self.modalities:
+            if m not in samples and f"{m}_embeds" not in samples:
+                continue
+            raw, idx, bs, num = self._encode(samples, m)
+            lo, hi = parallel.shard_range(bs * num, rank, ws)
+            if idx is None:
+                embeds[m] = raw[lo:hi]
+            else:
+                embeds[m], index[m] = raw, idx[lo:hi]
+        if bs is None:
+            raise MraError("samples holds none of the model's modalities")
+        if self.compat_repeat:   # reference :287-288  ids.repeat(num, 1): row k carries prompt k % bs
+            ids_n, tm_n = ids.repeat(num, 1), tmask.repeat(num, 1)
+        else:                    # aligned: row k carries the prompt of its own sample k // num
+            ids_n, tm_n = ids.repeat_interleave(num, 0), tmask.repeat_interleave(num, 0)
+        lo, hi = parallel.shard_range(bs * num, rank, ws)
+        return self.fuse_score(embeds, ids_n[lo:hi], tm_n[lo:hi], bs, num, index=index or None, want_llm=want_llm, want_full=want_full)
+
+    @torch.no_grad()
+    def generate(self, samples) -> List[str]:
+        """Reference ``:221-397`` with the LLM decode replaced by the scorer: one ``"[[start, end]]"``
+        string (seconds) per sample."""
+        out = self.encode_fuse(samples)
+        spans = out["spans"].cpu().tolist()
+        ts = samples.get("timestamps")
+        if ts is None:
+            ts = [list(range(out["num"]))] * out["bs"]
+        ts = [t.tolist() if torch.is_tensor(t) else list(t) for t in ts]
+        return [o.strip() for o in scorer.spans_to_text(spans, ts)]
+
+    def forward(self, samples):
+        """Reference ``:399-606`` returns the LLM's cross-entropy.  Without an LLM on this path the
+        training signal is build-defined: binary cross-entropy between sigmoid(20 * fused logit) and
+        clip membership of the target span parsed from ``text_output``.  Forward only (the Q-Former is
+        frozen in the reference, ``:196-204``; backward kernels are a later row)."""
+        if samples is None or samples == {} or not any(m in samples or f"{m}_embeds" in samples for m in self.modalities):
+            return {"loss": torch.tensor(0.0)}
+        out = self.encode_fuse(samples)
+        bs, num = out["bs"], out["num"]
+        target = torch.zeros(bs, num, dtype=torch.float32, device=self._device)
+        ts = samples.get("timestamps") or [list(range(num))] * bs
+        for r, txt in enumerate(samples.get("text_output", ["[[-1, -1]]"] * bs)):
+            nums = [int(x) for x in re.findall(r"-?\d+", txt)][:2]
+            if len(nums) == 2 and nums[0] >= 0:
+                t = torch.as_tensor(ts[r], dtype=torch.float32, device=self._device)
+                target[r] = ((t >= nums[0]) & (t <= nums[1])).float()
+        logits = out["fused"].view(bs, num) * 20.0
+        return {"loss": nn.functional.binary_cross_entropy_with_logits(logits, target)}
+
+
+def _ref(obj):
+    import weakref
+    return weakref.ref(obj)

@@ -1,0 +1,339 @@
+"""Host-side mirror of the LAVIS Q-Former the reference drives, executing on the HIP extension.
+
+Reference interface kept (``models/xinstructblip.py:286-293``)::
+
+    out = model.video_Qformer.bert(input_ids, attention_mask=..., query_embeds=...,
+                                   encoder_hidden_states=..., encoder_attention_mask=...,
+                                   return_dict=True)
+    out.last_hidden_state            # [N, 32 + L, 768]
+
+``QFormer`` is an ``nn.Module`` whose parameter tree reproduces the LAVIS checkpoint key names
+(``bert.embeddings.word_embeddings.weight``, ``bert.encoder.layer.{i}.attention.self.query.weight``
+... reference loader ``models/xinstructblip.py:644-653``) so ``state_dict()`` /
+``load_state_dict()`` / ``.to()`` behave as the reference's callers expect.  The modules are
+parameter containers only: all arithmetic happens in ``libmra_hip.so``; torch provides device
+memory and the stream.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import MRA_BF16, MRA_F16, MRA_F32, MraError, check, current_stream, lib, mra_cfg, ptr
+
+
+@dataclass
+class QFormerConfig:
+    """BERT-base + cross-attention every 2nd layer (reference ``models/xinstructblip.py:614-627``)."""
+
+    hidden: int = 768
+    heads: int = 12
+    inter: int = 3072
+    layers: int = 12
+    cross_freq: int = 2
+    enc_width: int = 1408
+    n_query: int = 32
+    vocab: int = 30523
+    max_pos: int = 512
+    ln_eps: float = 1e-12
+    enc_ln_eps: float = 1e-5
+    llm_hidden: int = 4096
+    op_dtype: torch.dtype = torch.float16  # MFMA operand type; accumulation/residual/LN stay fp32
+
+    def to_c(self) -> mra_cfg:
+        return mra_cfg(self.hidden, self.heads, self.inter, self.layers, self.cross_freq, self.enc_width, self.n_query,
+                       self.vocab, self.max_pos, self.ln_eps, self.enc_ln_eps, self.llm_hidden,
+                       MRA_BF16 if self.op_dtype == torch.bfloat16 else MRA_F16)
+
+
+class _Lin(nn.Module):
+    def __init__(self, out_f: int, in_f: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_f), requires_grad=False)
+
+
+class _LN(nn.Module):
+    def __init__(self, n: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(n), requires_grad=False)
+
+
+class _Emb(nn.Module):
+    def __init__(self, n: int, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d), requires_grad=False)
+
+
+class _Wrap(nn.Module):
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            self.add_module(k, v)
+
+
+def _attention(h: int, kv_width: int) -> nn.Module:
+    self_ = _Wrap(query=_Lin(h, h), key=_Lin(h, kv_width), value=_Lin(h, kv_width))
+    out = _Wrap(dense=_Lin(h, h), LayerNorm=_LN(h))
+    m = nn.Module()
+    m.add_module("self", self_)
+    m.add_module("output", out)
+    return m
+
+
+class _Bert(nn.Module):
+    """``qformer.bert``: parameter container named like LAVIS' ``BertModel`` whose call signature is
+    the one the reference uses (``models/xinstructblip.py:286-293``)."""
+
+    def __init__(self, embeddings: nn.Module, encoder: nn.Module):
+        super().__init__()
+        self.embeddings = embeddings
+        self.encoder = encoder
+        object.__setattr__(self, "_owner_ref", None)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, query_embeds=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, return_dict=True, **unused):
+        o = self._owner_ref()
+        if encoder_hidden_states is None:
+            raise ValueError("encoder_hidden_states must be given for cross-attention layers")
+        if query_embeds is None:
+            raise ValueError("You have to specify query_embeds")
+        if position_ids is not None:
+            raise NotImplementedError("custom position_ids are not supported (the reference never passes them)")
+        if encoder_attention_mask is not None and not bool(encoder_attention_mask.to(torch.bool).all()):
+            raise NotImplementedError("encoder_attention_mask with zeros is not supported: the reference always "
+                                      "passes all ones (models/xinstructblip.py:266,275)")
+        res = o.forward_fused(input_ids, attention_mask, encoder_hidden_states, query_embeds=query_embeds,
+                              want_query=False, want_full=True)
+        out = QFormerOutput(res["full"])
+        return out if return_dict else (out.last_hidden_state,)
+
+
+def _bert_tree(cfg: QFormerConfig) -> "_Bert":
+    emb = _Wrap(word_embeddings=_Emb(cfg.vocab, cfg.hidden), position_embeddings=_Emb(cfg.max_pos, cfg.hidden),
+                LayerNorm=_LN(cfg.hidden))
+    layers = nn.ModuleList()
+    for i in range(cfg.layers):
+        lay = nn.Module()
+        lay.add_module("attention", _attention(cfg.hidden, cfg.hidden))
+        if i % cfg.cross_freq == 0:
+            lay.add_module("crossattention", _attention(cfg.hidden, cfg.enc_width))
+        lay.add_module("intermediate", _Wrap(dense=_Lin(cfg.inter, cfg.hidden)))
+        lay.add_module("output", _Wrap(dense=_Lin(cfg.hidden, cfg.inter), LayerNorm=_LN(cfg.hidden)))
+        lay.add_module("intermediate_query", _Wrap(dense=_Lin(cfg.inter, cfg.hidden)))
+        lay.add_module("output_query", _Wrap(dense=_Lin(cfg.hidden, cfg.inter), LayerNorm=_LN(cfg.hidden)))
+        layers.append(lay)
+    return _Bert(emb, _Wrap(layer=layers))
+
+
+def seeded_parameter_order(cfg: QFormerConfig) -> List[Tuple[str, str]]:
+    """(key, kind) in the order the seeded synthetic init draws tensors; kind in w/b/g/z
+    (matrix, bias, LayerNorm gain, LayerNorm bias).  Same order as the checker's recipe."""
+    out = [("bert.embeddings.word_embeddings.weight", "w"), ("bert.embeddings.position_embeddings.weight", "w"),
+           ("bert.embeddings.LayerNorm.weight", "g"), ("bert.embeddings.LayerNorm.bias", "z")]
+    for i in range(cfg.layers):
+        p = f"bert.encoder.layer.{i}."
+        blocks = ["attention"] + (["crossattention"] if i % cfg.cross_freq == 0 else [])
+        for blk in blocks:
+            for n in ("query", "key", "value"):
+                out += [(p + f"{blk}.self.{n}.weight", "w"), (p + f"{blk}.self.{n}.bias", "b")]
+            out += [(p + f"{blk}.output.dense.weight", "w"), (p + f"{blk}.output.dense.bias", "b"),
+                    (p + f"{blk}.output.LayerNorm.weight", "g"), (p + f"{blk}.output.LayerNorm.bias", "z")]
+        for suf in ("", "_query"):
+            out += [(p + f"intermediate{suf}.dense.weight", "w"), (p + f"intermediate{suf}.dense.bias", "b"),
+                    (p + f"output{suf}.dense.weight", "w"), (p + f"output{suf}.dense.bias", "b"),
+                    (p + f"output{suf}.LayerNorm.weight", "g"), (p + f"output{suf}.LayerNorm.bias", "z")]
+    return out
+
+
+def draw_seeded(gen: torch.Generator, shape, kind: str, perturb: bool) -> torch.Tensor:
+    """One tensor of the synthetic init: matrices N(0, 0.02) (``initializer_range``, reference
+    ``models/xinstructblip.py:627``); biases 0, LayerNorm 1/0 -- or, with ``perturb``, biases
+    N(0, 0.02), gains 1 + N(0, 0.1), LayerNorm biases N(0, 0.05) so every parameter matters."""
+    if kind == "w":
+        return torch.randn(shape, generator=gen, dtype=torch.float32) * 0.02
+    if kind == "b":
+        return torch.randn(shape, generator=gen) * 0.02 if perturb else torch.zeros(shape)
+    if kind == "g":
+        return 1.0 + torch.randn(shape, generator=gen) * 0.1 if perturb else torch.ones(shape)
+    return torch.randn(shape, generator=gen) * 0.05 if perturb else torch.zeros(shape)
+
+
+class QFormerOutput:
+    """What the reference reads from the LAVIS model output (``.last_hidden_state``, ``:303``)."""
+
+    def __init__(self, last_hidden_state: torch.Tensor):
+        self.last_hidden_state = last_hidden_state
+        self.pooler_output = None
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state,)[i]
+
+
+class QFormer(nn.Module):
+    """One modality Q-Former on one GPU (one ``mra_qformer`` handle)."""
+
+    def __init__(self, cfg: QFormerConfig, device: Optional[torch.device] = None):
+        super().__init__()
+        self.cfg = cfg
+        self.bert = _bert_tree(cfg)
+        object.__setattr__(self.bert, "_owner_ref", weakref.ref(self))
+        self._handle = C.c_void_p()
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._ws: Optional[torch.Tensor] = None
+        self._dirty = True
+        with torch.cuda.device(self._device):
+            c = cfg.to_c()
+            check(lib().mra_qformer_create(C.byref(c), C.byref(self._handle)), "mra_qformer_create")
+        self.bert.to(self._device)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        # LAVIS checkpoints also carry the position_ids buffer and the LM head the reference deletes
+        # (``modality_qformer.cls = None``, models/xinstructblip.py:135)
+        sd = {k: v for k, v in state_dict.items() if k != "bert.embeddings.position_ids" and not k.startswith("cls.")}
+        res = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._dirty = True
+        return res
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._dirty = True
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib().mra_qformer_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights -> handle ---------------------------------------------------------------------
+    def push(self, name: str, t: torch.Tensor) -> None:
+        """Copy one tensor into the handle under its ABI name (``include/mra.h`` mra_qformer_load)."""
+        t = t.detach()
+        if t.device != self._device:
+            t = t.to(self._device)
+        if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        with torch.cuda.device(self._device):
+            check(lib().mra_qformer_load(self._handle, name.encode(), ptr(t), _lib.mra_dtype(t.dtype), shape, t.dim(),
+                                         current_stream()), f"mra_qformer_load({name})")
+
+    def sync_weights(self) -> None:
+        if not self._dirty:
+            return
+        for k, v in self.bert.state_dict(prefix="bert.").items():
+            self.push(k, v)
+        self._dirty = False
+
+    def missing(self) -> List[str]:
+        buf = C.create_string_buffer(1 << 16)
+        n = lib().mra_qformer_missing(self._handle, buf, len(buf))
+        return [s for s in buf.value.decode().split(",") if s] if n else []
+
+    @torch.no_grad()
+    def init_seeded_(self, seed: int = 0, perturb: bool = False, gen: Optional[torch.Generator] = None) -> torch.Generator:
+        """Synthetic weights (no pretrained checkpoints exist offline).  Drawn on the CPU from one
+        generator in ``seeded_parameter_order`` so that every machine derives the same tensors."""
+        g = gen if gen is not None else torch.Generator().manual_seed(seed)
+        sd = self.bert.state_dict(prefix="bert.", keep_vars=True)
+        for key, kind in seeded_parameter_order(self.cfg):
+            p = sd[key]
+            p.data.copy_(draw_seeded(g, tuple(p.shape), kind, perturb))
+        self._dirty = True
+        return g
+
+    # ---- ops -----------------------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+        return self._ws
+
+    def modality_ln(self, x: torch.Tensor, item_index: Optional[torch.Tensor] = None, items: Optional[int] = None) -> torch.Tensor:
+        """A2 + A3: ``ln(encoder(frame))`` then ``cat(embeds)[indices]`` (reference ``:265,281-285``).
+        x [src_items, tokens, E] f32/f16/bf16 -> [items, tokens, E] operand dtype."""
+        if x.dim() != 3 or x.shape[-1] != self.cfg.enc_width:
+            raise MraError(f"modality_ln expects [items, tokens, {self.cfg.enc_width}], got {tuple(x.shape)}")
+        x = x.contiguous()
+        n = int(items if items is not None else (item_index.numel() if item_index is not None else x.shape[0]))
+        if item_index is not None:
+            item_index = item_index.to(device=x.device, dtype=torch.int64).contiguous()
+        out = torch.empty((n, x.shape[1], x.shape[2]), dtype=self.cfg.op_dtype, device=x.device)
+        with torch.cuda.device(self._device):
+            check(lib().mra_modality_ln(self._handle, ptr(x), _lib.mra_dtype(x.dtype), ptr(item_index), n, x.shape[1],
+                                        ptr(out), current_stream()), "mra_modality_ln")
+        return out
+
+    def forward_fused(self, input_ids: Optional[torch.Tensor], attention_mask: Optional[torch.Tensor], enc: torch.Tensor,
+                      query_embeds: Optional[torch.Tensor] = None, want_query: bool = True, want_full: bool = False,
+                      want_cls: bool = False) -> Dict[str, torch.Tensor]:
+        """A4 on the extension.  enc [N, Kv, E] in the operand dtype (``modality_ln`` output).
+        Returns a dict with ``query`` [N,32,H], ``full`` [N,32+L,H], ``cls`` [N,H] (fp32) as requested."""
+        self.sync_weights()
+        cfg = self.cfg
+        if enc.dim() != 3 or enc.shape[-1] != cfg.enc_width:
+            raise MraError(f"encoder_hidden_states must be [N, Kv, {cfg.enc_width}], got {tuple(enc.shape)}")
+        if enc.dtype != cfg.op_dtype:
+            enc = enc.to(cfg.op_dtype)
+        enc = enc.contiguous()
+        N, Kv = int(enc.shape[0]), int(enc.shape[1])
+        L = 0 if input_ids is None else int(input_ids.shape[1])
+        dev = enc.device
+        if input_ids is not None:
+            if input_ids.shape[0] != N:
+                raise MraError(f"input_ids has {input_ids.shape[0]} rows, encoder_hidden_states {N}")
+            input_ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != (N, cfg.n_query + L):
+                raise MraError(f"attention_mask must be [{N}, {cfg.n_query + L}], got {tuple(attention_mask.shape)}")
+            attention_mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        q_items = 0
+        if query_embeds is not None:
+            if query_embeds.dim() != 3 or tuple(query_embeds.shape[1:]) != (cfg.n_query, cfg.hidden) or query_embeds.shape[0] not in (1, N):
+                raise MraError(f"query_embeds must be [1 or {N}, {cfg.n_query}, {cfg.hidden}]")
+            query_embeds = query_embeds.to(device=dev, dtype=torch.float32).contiguous()
+            q_items = int(query_embeds.shape[0])
+        out: Dict[str, torch.Tensor] = {}
+        if N == 0:
+            return {"query": torch.empty(0, cfg.n_query, cfg.hidden, device=dev), "full": torch.empty(0, cfg.n_query + L, cfg.hidden, device=dev),
+                    "cls": torch.empty(0, cfg.hidden, device=dev)}
+        if want_query:
+            out["query"] = torch.empty(N, cfg.n_query, cfg.hidden, dtype=torch.float32, device=dev)
+        if want_full:
+            out["full"] = torch.empty(N, cfg.n_query + L, cfg.hidden, dtype=torch.float32, device=dev)
+        if want_cls:
+            out["cls"] = torch.empty(N, cfg.hidden, dtype=torch.float32, device=dev)
+        with torch.cuda.device(self._device):
+            nbytes = int(lib().mra_qformer_workspace_bytes(self._handle, N, L, Kv))
+            ws = self._workspace(nbytes)
+            check(lib().mra_qformer_forward(self._handle, ptr(input_ids), ptr(attention_mask), ptr(query_embeds), q_items,
+                                            ptr(enc), N, L, Kv, ptr(out.get("query")), ptr(out.get("full")),
+                                            ptr(out.get("cls")), ptr(ws), ws.numel(), current_stream()),
+                  "mra_qformer_forward")
+        return out
+
+    def llm_proj(self, z: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """A5: ``{modality}_llm_proj(last_hidden_state[:, :32, :])`` (reference ``:303``)."""
+        cfg = self.cfg
+        zz = z.reshape(-1, cfg.hidden).to(torch.float32).contiguous()
+        rows = int(zz.shape[0])
+        out = torch.empty(rows, cfg.llm_hidden, dtype=out_dtype, device=zz.device)
+        ws = self._workspace(max(256, rows * cfg.hidden * 2 + 256))
+        with torch.cuda.device(self._device):
+            check(lib().mra_llm_proj(self._handle, ptr(zz), rows, ptr(out), _lib.mra_dtype(out_dtype), ptr(ws), ws.numel(),
+                                     current_stream()), "mra_llm_proj")
+        return out.reshape(*z.shape[:-1], cfg.llm_hidden)
+
+    def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
+        return float(lib().mra_qformer_flops(self._handle, items, L, kv, int(with_last_text)))

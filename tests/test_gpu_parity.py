@@ -1,0 +1,314 @@
+"""Parity tests proper (``-m gpu``): the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Tolerances (north_star: similarity logits within 1e-3 relative; integer spans bit-exact):
+  * hidden states: MFMA operands are f16 (11-bit significand), everything else fp32; 12 layers of
+    f16-operand GEMMs land at ~1e-3 of the hidden-state scale -> max|d| <= 1e-2 on |z| <= ~8.
+  * similarity logits: |d| <= 1e-3 * max|logit| (relative to the logit scale), asserted below.
+  * integers (spans, reorder): exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qformer_ref as O
+from tools.make_golden import CASES, make_inputs
+
+pytestmark = pytest.mark.gpu
+
+Z_ATOL = 1e-2
+LOGIT_RTOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def build_qformer(dev, enc_width, seed, perturb=True, op_dtype=torch.float16, **over):
+    from mraudio_amd.qformer import QFormer, QFormerConfig, draw_seeded
+
+    cfg = QFormerConfig(enc_width=enc_width, op_dtype=op_dtype, **over)
+    qf = QFormer(cfg, device=dev)
+    g = qf.init_seeded_(seed=seed, perturb=perturb)
+    extras = {
+        "query_tokens": draw_seeded(g, (1, cfg.n_query, cfg.hidden), "w", perturb),
+        "ln.weight": draw_seeded(g, (enc_width,), "g", perturb),
+        "ln.bias": draw_seeded(g, (enc_width,), "z", perturb),
+        "llm_proj.weight": draw_seeded(g, (cfg.llm_hidden, cfg.hidden), "w", perturb),
+        "llm_proj.bias": draw_seeded(g, (cfg.llm_hidden,), "b", perturb),
+    }
+    for k, v in extras.items():
+        qf.push(k, v)
+    qf.sync_weights()
+    assert qf.missing() == []
+    return qf, cfg
+
+
+def oracle_cfg(cfg):
+    return O.QFormerCfg(hidden=cfg.hidden, heads=cfg.heads, inter=cfg.inter, layers=cfg.layers, cross_freq=cfg.cross_freq,
+                        enc_width=cfg.enc_width, vocab=cfg.vocab, max_pos=cfg.max_pos, llm_hidden=cfg.llm_hidden)
+
+
+@pytest.fixture(scope="module")
+def video(dev):
+    qf, cfg = build_qformer(dev, 1408, seed=0)
+    return qf, cfg, O.init_weights(oracle_cfg(cfg), seed=0, perturb=True)
+
+
+@pytest.fixture(scope="module")
+def audio(dev):
+    qf, cfg = build_qformer(dev, 768, seed=1)
+    return qf, cfg, O.init_weights(oracle_cfg(cfg), seed=1, perturb=True)
+
+
+def test_extension_is_the_hip_library():
+    from mraudio_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH)
+    assert b"gfx950" in _lib.lib().mra_version()
+
+
+def test_modality_ln_and_reorder(video, dev):
+    qf, cfg, w = video
+    g = torch.Generator().manual_seed(3)
+    bs, num, kv = 2, 3, 257
+    frames = [torch.randn(bs, kv, 1408, generator=g) * 2 + 0.5 for _ in range(num)]  # per-position encoder outputs
+    raw = torch.cat(frames)
+    idx = torch.tensor(O.reorder_indices(bs, num))
+    ref = O.modality_layernorm(raw, w["ln.weight"], w["ln.bias"])[idx]
+    for dt, tol in ((torch.float32, 2e-3), (torch.float16, 4e-3)):
+        got = qf.modality_ln(raw.to(dev).to(dt), item_index=idx.to(dev)).float().cpu()
+        ref_dt = O.modality_layernorm(raw.to(dt).float(), w["ln.weight"], w["ln.bias"])[idx]
+        assert got.shape == ref.shape
+        assert (got - ref_dt).abs().max().item() < tol  # f16 output rounding of |y| <~ 6
+    # identity index == no index
+    a = qf.modality_ln(raw.to(dev))
+    b = qf.modality_ln(raw.to(dev), item_index=torch.arange(bs * num, device=dev))
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_qformer_matches_golden_and_oracle(name, video, audio, dev, golden_dir):
+    E, kv, n, L, wseed, iseed, ragged = CASES[name]
+    qf, cfg, w = video if E == 1408 else audio
+    ocfg = oracle_cfg(cfg)
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, iseed, ragged)
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, name + ".npz"))["last_hidden_state"])
+    enc = qf.modality_ln(feats.to(dev))
+    res = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_full=True, want_cls=True)
+    full = res["full"].cpu()
+    valid = att.bool()
+    assert (full - gold)[valid].abs().max().item() < Z_ATOL
+    assert torch.equal(res["query"].cpu(), full[:, :32])
+    assert torch.equal(res["cls"].cpu(), full[:, 32])
+    # the cheap variants (no last-layer text FFN / [CLS] row only) give the same numbers
+    only_q = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"].cpu()
+    assert torch.equal(only_q, full[:, :32])
+    q_cls = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
+    assert torch.equal(q_cls["query"].cpu(), full[:, :32])
+    assert (q_cls["cls"].cpu() - full[:, 32]).abs().max().item() < 1e-5
+    # oracle run on the exact f16-rounded features the kernel saw: isolates Q-Former error
+    enc_ref = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"])
+    h = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(n, -1, -1), enc_ref)
+    assert (full - h)[valid].abs().max().item() < Z_ATOL
+    rel = ((full - h)[valid].norm() / h[valid].norm()).item()
+    assert rel < 2e-3, rel
+
+
+def test_bert_call_signature_like_the_reference(video, dev):
+    qf, cfg, w = video
+    ocfg = oracle_cfg(cfg)
+    n, L, kv = 2, 6, 40
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 21, True)
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"])
+    q = w["query_tokens"].expand(n, -1, -1)
+    out = qf.bert(ids.to(dev), attention_mask=att.to(dev), query_embeds=q.to(dev).repeat(1, 1, 1),
+                  encoder_hidden_states=enc.to(dev), encoder_attention_mask=torch.ones(n, kv, dtype=torch.long, device=dev),
+                  return_dict=True)
+    h = O.qformer_forward(w, ocfg, ids, att, q, enc)
+    assert out.last_hidden_state.shape == (n, 32 + L, 768)
+    assert (out.last_hidden_state.cpu() - h)[att.bool()].abs().max().item() < Z_ATOL
+    # a different query_embeds tensor per item is honoured
+    q2 = q.clone()
+    q2[1] = q2[1] * 1.5
+    out2 = qf.bert(ids.to(dev), attention_mask=att.to(dev), query_embeds=q2.to(dev), encoder_hidden_states=enc.to(dev))
+    h2 = O.qformer_forward(w, ocfg, ids, att, q2, enc)
+    assert (out2.last_hidden_state.cpu() - h2)[att.bool()].abs().max().item() < Z_ATOL
+    with pytest.raises(ValueError):
+        qf.bert(ids.to(dev), attention_mask=att.to(dev), query_embeds=q.to(dev))
+    with pytest.raises(NotImplementedError):
+        bad = torch.ones(n, kv, dtype=torch.long, device=dev)
+        bad[0, 3] = 0
+        qf.bert(ids.to(dev), attention_mask=att.to(dev), query_embeds=q.to(dev), encoder_hidden_states=enc.to(dev),
+                encoder_attention_mask=bad)
+
+
+def test_edge_cases(video, dev):
+    from mraudio_amd import MraError
+
+    qf, cfg, w = video
+    ocfg = oracle_cfg(cfg)
+    # empty batch
+    e = qf.forward_fused(torch.zeros(0, 4, dtype=torch.long, device=dev), None, torch.zeros(0, 5, 1408, device=dev, dtype=torch.float16))
+    assert e["query"].shape == (0, 32, 768)
+    # no text (L = 0), one encoder token (kv = 1), one item
+    g = torch.Generator().manual_seed(9)
+    enc = torch.randn(1, 1, 1408, generator=g)
+    q = w["query_tokens"].expand(1, -1, -1)
+    got = qf.forward_fused(None, None, enc.to(dev).half(), want_query=True)["query"].cpu()
+    ref = O.qformer_forward(w, ocfg, torch.zeros(1, 0, dtype=torch.long), torch.ones(1, 32, dtype=torch.long), q, enc.half().float())
+    assert (got - ref).abs().max().item() < Z_ATOL
+    # longest prompt the reference allows (max_txt_len 128 -> S = 160), heavy padding on one row
+    n, L, kv = 2, 128, 33
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 5, False)
+    att[1, 32 + 7:] = 0
+    encf = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"])
+    full = qf.forward_fused(ids.to(dev), att.to(dev), encf.to(dev).half(), want_full=True)["full"].cpu()
+    ref = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(n, -1, -1), encf.half().float())
+    assert (full - ref)[att.bool()].abs().max().item() < Z_ATOL
+    # bad shapes fail loudly
+    with pytest.raises(MraError):
+        qf.forward_fused(ids.to(dev), att[:, :-1].to(dev), encf.to(dev).half())
+    with pytest.raises(MraError):
+        qf.forward_fused(ids.to(dev), att.to(dev), encf[..., :100].to(dev).half())
+    with pytest.raises(MraError):
+        qf.push("bert.not.a.parameter", torch.zeros(4, device=dev))
+
+
+def test_llm_projection(video, dev):
+    qf, cfg, w = video
+    g = torch.Generator().manual_seed(4)
+    bs, num = 2, 3
+    z = torch.randn(bs * num, 32 + 5, 768, generator=g)
+    ref = O.llm_project(z, w, bs, num)
+    got = qf.llm_proj(z[:, :32].to(dev)).reshape(bs, num * 32, -1).cpu()
+    assert got.shape == ref.shape == (bs, num * 32, 4096)
+    assert (got - ref).abs().max().item() < 3e-3  # |y| ~ 0.6, f16 operands
+
+
+def test_scorer_fuse_span_bit_exact_integers(dev):
+    from mraudio_amd import scorer
+
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(40, 32, 768, generator=g)
+    t = torch.randn(40, 768, generator=g)
+    sim_r, logit_r = O.cosine_scores(z, t)
+    sim, logit = scorer.cosine_scores(z.to(dev), t.to(dev))
+    assert (sim.cpu() - sim_r).abs().max().item() < 1e-6 and (logit.cpu() - logit_r).abs().max().item() < 1e-6
+    _, logit1 = scorer.cosine_scores(z.to(dev), t[:1].to(dev), want_sim=False)
+    assert (logit1.cpu() - O.cosine_scores(z, t[:1])[1]).abs().max().item() < 1e-6
+    # fusion + span on IDENTICAL fp32 logits must be bit-exact / integer-exact
+    a, b = torch.randn(60, generator=g), torch.randn(60, generator=g)
+    for wts in (None, (0.3, 0.7)):
+        fr = O.fuse_logits([a, b], wts)
+        fg = scorer.fuse_logits([a.to(dev), b.to(dev)], wts).cpu()
+        assert torch.equal(fr, fg)
+    x = torch.randn(7, 61, generator=g)
+    x[2, 5] = x[2, 40] = 9.0          # tie -> first argmax
+    x[3] = 1.25                        # constant row -> whole video
+    for alpha in (0.5, 0.1, 0.9):
+        got = scorer.spans_from_logits(x.reshape(-1).to(dev), 7, 61, alpha).cpu().tolist()
+        ref = [list(O.span_from_logits(x[v], alpha)) for v in range(7)]
+        assert got == ref
+    assert scorer.spans_to_text([(1, 3)], [[0, 2, 5, 7]]) == O.spans_to_text([(1, 3)], [[0, 2, 5, 7]])
+
+
+def test_end_to_end_encode_fuse_score_vs_oracle(dev):
+    """BASELINE config 3 shape at small N: both modalities, LN -> Q-Former -> score -> fuse -> span."""
+    from mraudio_amd.models.xinstructblip import ENC_WIDTH, XInstructBLIP
+
+    model = XInstructBLIP(seed=0, perturb=True, device=dev)
+    bs, num = 2, 3
+    g = torch.Generator().manual_seed(17)
+    feats = {"video": torch.randn(bs, num, 257, 1408, generator=g), "audio": torch.randn(bs, num, 256, 768, generator=g)}
+    prompts = ["Query: a person opens the door.\nRelevant windows: ", "Query: someone is cooking in the kitchen while music plays.\nRelevant windows: "]
+    samples = {"video_embeds": feats["video"], "audio_embeds": feats["audio"], "text_input": prompts,
+               "timestamps": [[0, 3, 6], [1, 4, 8]], "duration": [9, 10]}
+    out = model.encode_fuse(samples, want_llm=True)
+    text = model.tokenizer(prompts, padding="longest", truncation=True, max_length=128, return_tensors="pt")
+    rows = O.repeat_text_rows(bs, num)       # the reference's .repeat(T, 1) pairing
+    ids, tm = text.input_ids[rows], text.attention_mask[rows]
+    assert torch.equal(ids, text.input_ids.repeat(num, 1))
+    cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
+    ws = {"video": O.init_weights(cfgs["video"], seed=0, perturb=True), "audio": O.init_weights(cfgs["audio"], seed=1, perturb=True)}
+    ref = O.encode_fuse_score(ws, cfgs, {m: feats[m].reshape(bs * num, *feats[m].shape[2:]) for m in ("audio", "video")}, ids, tm, bs, num)
+    for m in ("video", "audio"):
+        assert (out["z"][m].cpu() - ref["z"][m]).abs().max().item() < Z_ATOL
+        scale = ref["logit"][m].abs().max().item()
+        assert (out["logit"][m].cpu() - ref["logit"][m]).abs().max().item() <= LOGIT_RTOL * scale, (m, scale)
+        assert (out["sim"][m].cpu() - ref["sim"][m]).abs().max().item() <= LOGIT_RTOL * ref["sim"][m].abs().max().item()
+        yl = O.llm_project(torch.cat([ref["z"][m], torch.zeros(bs * num, 1, 768)], 1), ws[m], bs, num)
+        assert (out["inputs_llm"][m].cpu() - yl).abs().max().item() < 5e-3
+        assert out["atts_llm"][m].shape == (bs, num * 32)
+    scale = ref["fused"].abs().max().item()
+    assert (out["fused"].cpu() - ref["fused"]).abs().max().item() <= LOGIT_RTOL * scale
+    assert [tuple(s) for s in out["spans"].cpu().tolist()] == [tuple(s) for s in ref["spans"]]
+    strings = model.generate(samples)
+    assert strings == O.spans_to_text(ref["spans"], samples["timestamps"])
+    from mraudio_amd.utils import spans as sp
+    assert all(sp.moment_str_to_list(sp.post_process(s))[0][0] >= 0 for s in strings)
+    # checkpoint key names of the reference round-trip through load_state_dict
+    sd = model.state_dict()
+    for k in ("video_Qformer.bert.encoder.layer.0.crossattention.self.key.weight", "audio_Qformer.bert.embeddings.LayerNorm.bias",
+              "video_query_tokens", "audio_ln.weight", "video_llm_proj.bias", "audio_Qformer.bert.encoder.layer.11.output_query.dense.weight"):
+        assert k in sd, k
+    assert sd["video_Qformer.bert.encoder.layer.0.crossattention.self.key.weight"].shape == (768, 1408)
+    assert "video_Qformer.bert.encoder.layer.1.crossattention.self.key.weight" not in sd
+    msg = model.load_state_dict(sd, strict=True)
+    assert list(msg.missing_keys) == [] and list(msg.unexpected_keys) == []
+    again = model.encode_fuse(samples)
+    assert torch.equal(again["fused"], out["fused"])
+    # aligned text pairing differs from the reference's quirk only when prompts differ
+    assert model.forward({})["loss"].item() == 0.0
+
+
+def test_full_size_properties(video, dev):
+    """BASELINE sizes (32 clips; 32-frame clips = 8224 video tokens): properties that need no oracle
+    run, plus an oracle spot check of two items at Kv = 8224."""
+    qf, cfg, w = video
+    ocfg = oracle_cfg(cfg)
+    n, L, kv = 32, 32, 257
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 31, False)
+    enc = qf.modality_ln(feats.to(dev))
+    z = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
+    assert torch.isfinite(z["query"]).all()
+    # items are independent: a permutation of the batch permutes the output (same tiles, same order of
+    # accumulation per element -> tight tolerance), and a half batch equals the matching half
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    zp = qf.forward_fused(ids[perm].to(dev), att[perm].to(dev), enc[perm.to(dev)], want_query=True)["query"]
+    assert (zp - z["query"][perm.to(dev)]).abs().max().item() < 1e-4
+    zh = qf.forward_fused(ids[:16].to(dev), att[:16].to(dev), enc[:16], want_query=True)["query"]
+    assert (zh - z["query"][:16]).abs().max().item() < 1e-4
+    # determinism
+    z2 = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    assert torch.equal(z2, z["query"])
+    # 32-frame clips: Kv = 32 * 257; two items against the oracle
+    n2, kv2 = 2, 8224
+    ids2, _, att2, feats2 = make_inputs(ocfg, n2, 16, kv2, 41, False)
+    enc2 = qf.modality_ln(feats2.to(dev))
+    got = qf.forward_fused(ids2.to(dev), att2.to(dev), enc2, want_query=True)["query"].cpu()
+    ref = O.qformer_forward(w, ocfg, ids2, att2, w["query_tokens"].expand(n2, -1, -1), O.modality_layernorm(feats2, w["ln.weight"], w["ln.bias"]))[:, :32]
+    assert (got - ref).abs().max().item() < Z_ATOL
+    # concatenating the SAME 257 tokens 32 times leaves softmax(QK)V unchanged: Kv = 8224 == Kv = 257
+    rep = feats[:2].repeat(1, 32, 1)
+    a = qf.forward_fused(ids[:2].to(dev), att[:2].to(dev), qf.modality_ln(rep.to(dev)), want_query=True)["query"]
+    assert (a - z["query"][:2]).abs().max().item() < 5e-3
+
+
+def test_bf16_operands_run_and_are_close(dev):
+    qf, cfg = build_qformer(dev, 768, seed=1, op_dtype=torch.bfloat16)
+    w = O.init_weights(oracle_cfg(cfg), seed=1, perturb=True)
+    ocfg = oracle_cfg(cfg)
+    ids, tmask, att, feats = make_inputs(ocfg, 2, 8, 64, 3, True)
+    enc = qf.modality_ln(feats.to(dev))
+    assert enc.dtype == torch.bfloat16
+    got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"].cpu()
+    ref = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(2, -1, -1), O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]))[:, :32]
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel  # bf16 has 8 significand bits: ~8x the f16 error; f16 is the default for that reason
