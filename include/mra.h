@@ -123,6 +123,11 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
 size_t mra_kv_cache_bytes(mra_qformer* h, int32_t items, int32_t kv);
 int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, void* kv_cache, void* stream);
 
+/* Optional instrumentation for bench.py: when both events (hipEvent_t passed as void*) are non-NULL,
+ * every following mra_qformer_forward records ev_start right before and ev_stop right after its
+ * K/V-projection launch, on the launch stream.  (NULL, NULL) switches it off. */
+int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
+
 /* ---- A5: LLM projection ---------------------------------------------------------------------------
  * replaces: {modality}_llm_proj(last_hidden_state[:, :32, :]) (models/xinstructblip.py:303).
  * z [rows, hidden] f32 -> out [rows, llm_hidden] of out_dtype (MRA_F32 or the operand dtype).

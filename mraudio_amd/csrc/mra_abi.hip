@@ -72,6 +72,7 @@ struct mra_qformer {
   float* bkv = nullptr;
   void* wllm = nullptr;
   float* bllm = nullptr;
+  hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
 };
 
@@ -430,8 +431,10 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
 
   // K/V of every cross layer in one GEMM, scattered head-major
   if (h->ncross > 0) {
+    if (h->kv_ev0 && h->kv_ev1) (void)hipEventRecord(h->kv_ev0, stream);
     rc = kv_project(h, enc, N, kv, w.kv16, stream);
     if (rc) return chk(rc, "kv projection gemm");
+    if (h->kv_ev0 && h->kv_ev1) (void)hipEventRecord(h->kv_ev1, stream);
   }
 
   const bool want_text_last = out_full != nullptr;
@@ -603,6 +606,14 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       }
     }
   }
+  return MRA_OK;
+}
+
+int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if ((ev_start == nullptr) != (ev_stop == nullptr)) return fail(MRA_EINVAL, "give both events or neither");
+  h->kv_ev0 = reinterpret_cast<hipEvent_t>(ev_start);
+  h->kv_ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
   return MRA_OK;
 }
 

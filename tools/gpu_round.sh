@@ -18,3 +18,8 @@ timeout -k 10 600 python bench.py --steps 5 --warmup 2 > $OUT/bench_$TAG.log 2>&
 tail -2 $OUT/bench_$TAG.log
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --workload ref --cpu-clips 32 > $OUT/bench_ref_$TAG.log 2>&1 || { echo "bench ref failed"; tail -20 $OUT/bench_ref_$TAG.log; exit 1; }
 tail -1 $OUT/bench_ref_$TAG.log
+# rocprof kernel trace of the bench command (summary copied to profiles/ by hand)
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python3 /root/repo/bench.py --steps 5 --warmup 2 --cpu-clips 0 > $OUT/prof_$TAG.log 2>&1 || { echo "rocprof failed"; tail -20 $OUT/prof_$TAG.log; exit 1; }
+tail -1 $OUT/prof_$TAG.log
+find $OUT/prof_$TAG -name "*stats*" | head
