@@ -46,6 +46,7 @@ struct GemmArgs {
   GemmProb p[2];
   int ngroups;
   int total_tiles;
+  unsigned long long* dbg;  // diagnostic builds only (gemm_set_debug_buffer): per-wave cycle sums
 };
 
 // Returns 0 on success, <0 on bad shapes.  All problems of one launch share dtype / epilogue.
@@ -53,6 +54,9 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
 // which tile config launch_gemm would pick (for tests / DESIGN.md): 0 = 64x64, 1 = 128x128, 2 = 256x256
 int gemm_pick_config(const GemmProb* probs, int ngroups);
 void gemm_force_config(int cfg);  // -1 = automatic (default)
+void gemm_set_debug_buffer(unsigned long long* dev_buf);  // variant 4 (stamped v1) writes 4 u64 per wave
+void gemm_force_variant(int v);   // 5 = default (warp-specialised 256x256, two-buffer small tiles); 0 ring, 1 two-buffer,
+                                  // 2 +L2 prefetch, 3 +spread DMA issue, 4 stamped diagnostic -- kept for A/B runs
 
 // ---- attention ------------------------------------------------------------------------------
 struct AttnArgs {

@@ -490,6 +490,33 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
+    test_gemm(cfg, EPI_RES_F32, OP_F16, 2 * t + 37, 2 * t, 192, true, 2);
+    test_gemm(cfg, EPI_KV, OP_F16, t + 10, 2 * t >= 256 ? 2 * t : 256, 64, false);
+  }
+  gemm_force_variant(2);                                 // v1 + L2 prefetch
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
+    test_gemm(cfg, EPI_RES_F32, OP_F16, 2 * t + 37, 2 * t, 320, true, 2);
+    test_gemm(cfg, EPI_KV, OP_F16, t + 10, 2 * t >= 256 ? 2 * t : 256, 64, false);
+  }
+  gemm_force_variant(3);                                 // v1 with the LDS-DMA issue spread over the MFMAs
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
+    test_gemm(cfg, EPI_RES_F32, OP_F16, 2 * t + 37, 2 * t, 320, true, 2);
+    test_gemm(cfg, EPI_KV, OP_F16, t + 10, 2 * t >= 256 ? 2 * t : 256, 64, false);
+  }
+  gemm_force_variant(5);                                 // warp-specialised 256x256 loop (8 compute + 4 loader waves)
+  test_gemm(2, EPI_RES_F32, OP_F16, 2 * 256 + 37, 512, 320, true, 2);
+  test_gemm(2, EPI_KV, OP_F16, 256 + 10, 512, 64, false);
+  test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
+  test_gemm(2, EPI_OP, OP_BF16, 300, 512, 192, false);
+  gemm_force_variant(0);                                 // ring loop
+  test_gemm(2, EPI_OP, OP_F16, 300, 512, 64, false);     // K = 64: fewer slots than the ring holds
+  test_gemm(0, EPI_OP, OP_F16, 100, 128, 3072, false);   // long K on the 8-slot ring
+  gemm_force_variant(5);
 
   // attention
   test_attention(OP_F16, 5, 3, 45, 45, true, 1);     // self, ragged masks, 2 query blocks (13 live rows in the 2nd)
