@@ -153,6 +153,13 @@ def main():
     achieved = kv_flops / (kv_step_ms * 1e-3) / 1e12  # priced on the in-step launches (timed region)
     del cache, enc
 
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_kvproj_ws.json")
+    if args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(pmc_file):
+        # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same kernel and shape
+        # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
+        traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+
     flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
 
     # ---- CPU baseline: the oracle (a CPU port of the same path) on a bounded sample ----
@@ -177,9 +184,10 @@ def main():
                 "weights": "synthetic BERT init, seed 0",
             },
             "tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<256x256, EPI_KV> (K/V projection of all cross layers)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_ws_kernel<256x256x64, EPI_KV> (K/V projection of all cross layers, video)",
                          "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None,
                          "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": kv_flops,
                          "standalone_launch_ms": round(kv_ms, 4), "standalone_tflops": round(kv_flops / (kv_ms * 1e-3) / 1e12, 1)},
             "cpu_baseline": cpu,

@@ -350,7 +350,7 @@ int launch_t(const AttnArgs& a, hipStream_t stream) {
     kfn = masked ? attn_kernel<T, true, 1> : attn_kernel<T, false, 1>;
     grid = dim3((nunits + 3) / 4);
   }
-  if (lds > 64 * 1024) {
+  if (lds > 64 * 1024) {  // (self-attention with very long prompts only; a plain attribute call, not a stream op)
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -3;
   }

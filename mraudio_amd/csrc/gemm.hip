@@ -21,6 +21,10 @@
 // and on the ds_read_b128 address: conflict-free for all four 16-lane groups.
 // Workgroups walk tiles in 8-row-tile panels after an XCD-contiguous remap so that the 32
 // concurrently running workgroups of one XCD share operand panels in that XCD's L2.
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "kernels.h"
 #include "mra_common.h"
 
@@ -142,29 +146,45 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
     }
   }
   __syncthreads();
-  // first row of the tile located once (one division), the rest by increments
+  // Copy-out.  q = tid + k * NT walks the LDS image linearly; with TM * 8 = RPB * NT chunks per column
+  // block a thread meets only RPB distinct rows (k % RPB) and one block per k / RPB, so the row's
+  // (item, row-in-item) split -- one division for the tile, increments per row -- and the 64-bit
+  // destination offsets are computed RPB times, not per chunk.
+  constexpr int NCH = TN * TM / 8;  // 16-byte chunks in the tile
+  static_assert(NCH % NT == 0 && (TM * 8) % NT == 0, "chunks must divide over the threads");
+  constexpr int RPB = TM * 8 / NT;  // rows a thread touches per column block
   const int rpi = EPI == EPI_KV ? P.kv_tokens : P.c.rpi;
   const int item0 = m0 / rpi, r0 = m0 - item0 * rpi;
-  constexpr int NCH = TN * TM / 8;  // 16-byte chunks in the tile
-  static_assert(NCH % NT == 0, "chunks must divide over the threads");
-#pragma unroll 4
-  for (int k = 0; k < NCH / NT; ++k) {
-    const int q = tid + k * NT;
-    const int hq = q / (TM * 8), rem = q - hq * (TM * 8);
-    const int row = rem >> 3, c = (rem & 7) ^ (row & 7);
-    if (m0 + row >= P.M) continue;
-    const typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
+  const int c = (tid & 7);
+  long long rowoff[RPB];
+  bool live[RPB];
+#pragma unroll
+  for (int u = 0; u < RPB; ++u) {
+    const int row = (tid >> 3) + u * (NT / 8);
+    live[u] = m0 + row < P.M;
     int item = item0, r = r0 + row;
     while (r >= rpi) { r -= rpi; ++item; }
+    const int cc = c ^ (row & 7);
+    if constexpr (EPI == EPI_KV) rowoff[u] = ((long long)item * P.kv_heads * P.kv_tokens + r) * 64 + cc * 8;
+    else rowoff[u] = (long long)item * P.c.item_stride + (long long)r * P.c.ld + cc * 8;
+  }
+#pragma unroll
+  for (int hq = 0; hq < TN / 64; ++hq) {
     const int nb = n0 + hq * 64;
+    long long blk;
     if constexpr (EPI == EPI_KV) {
       const int hidden = P.kv_heads * 64;
       const int sel = nb / hidden, head = (nb - sel * hidden) >> 6;
-      const long long dst = ((((long long)sel * P.kv_items + item) * P.kv_heads + head) * P.kv_tokens + r) * 64 + c * 8;
-      *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + dst) = val;
+      blk = ((long long)sel * P.kv_items * P.kv_heads + head) * P.kv_tokens * 64;
     } else {
-      const long long dst = (long long)item * P.c.item_stride + (long long)r * P.c.ld + nb + c * 8;
-      *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + dst) = val;
+      blk = nb;
+    }
+#pragma unroll
+    for (int u = 0; u < RPB; ++u) {
+      if (!live[u]) continue;
+      const int q = tid + (hq * RPB + u) * NT;
+      const typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
+      *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + blk + rowoff[u]) = val;
     }
   }
 }
@@ -476,7 +496,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // MFMAs between barriers; a loader issues tile kt+1 right after barrier kt and parks on vmcnt(0) until
 // barrier kt+1, off the compute waves' critical path.  Three waves per SIMD cap the kernel at 168
 // VGPRs: fragments are read just in time (all four B fragments, A one at a time).
-template <typename T, int EPI>
+template <typename T, int EPI, bool NODMA = false>  // NODMA: diagnostic only (wrong results): loaders stop after tile 1
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int TN = 256, TM = 256, BK = 64, ROWB = BK * 2;
   constexpr int WGM = 4, WTN = 128, WTM = 64, FN = 8, FM = 4;
@@ -519,7 +539,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      if (kt + 1 < nk && !(NODMA && kt >= 1)) stage((kt + 1) & 1, kt + 1);
     }
     if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
       __syncthreads();  // K loop reads over
@@ -573,16 +593,146 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   }
 }
 
+// =================================================================================================
+// ws2: warp-specialised 256x256, 4-slot LDS ring of 32-deep K slices, NO barrier in the K loop
+// =================================================================================================
+// With a barrier per K tile every compute wave restarts in lockstep: the two waves of a SIMD read
+// their first fragments at the same moment and the matrix pipe idles ~900 of ~3000 cycles per tile
+// ("ws without DMA" still stops at 1.25 PF).  Here loaders and compute waves hand slots over through
+// monotonic LDS counters instead: full[s] (+1 by the slot's loader wave when its DMA has landed:
+// vmcnt(0), then ds_add) and done[s] (+1 per compute wave after its last fragment read of the slot).
+// A compute wave waits for full[s] >= use + 1 -- the poll for the next slot is issued early and
+// normally already satisfied -- and never meets the other waves, so SIMD partners drift apart and
+// cover each other's read bubbles; loader wave s refills slot s once done[s] >= 8 * use, so up to 3
+// slots are in flight or landed ahead of the one being consumed.  Every spin is bounded (a hung grid would take the GPU down): on give-up the
+// kernel finishes with wrong data and sets args.dbg[0] if a debug buffer is installed.
+__device__ __forceinline__ bool spin_ge(volatile unsigned* p, unsigned target) {
+  for (int i = 0; i < (1 << 16); ++i) {  // ~5 ms; a real wait is a few microseconds
+    if (*p >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(768) gemm_ws2_kernel(const GemmArgs args) {
+  constexpr int TN = 256, TM = 256, SK = 32, SROW = SK * 2, NS = 4;
+  constexpr int WGM = 4, WTN = 128, WTM = 64, FN = 8, FM = 4;
+  constexpr int SLOT = (TN + TM) * SROW;  // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  volatile unsigned* full = reinterpret_cast<volatile unsigned*>(smem + NS * SLOT);
+  volatile unsigned* done = full + NS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n0, m0;
+  const GemmProb& P = pick_tile<TN, TM>(args, n0, m0);
+  const int K = P.K, M = P.M;
+  const int nslots = K / SK;
+  if (tid < 2 * NS) full[tid] = 0;
+  __syncthreads();
+  bool ok = true;
+
+  if (wave >= 8) {
+    // ------------------------------- loader waves -------------------------------
+    // loader lw owns ring slot lw: it refills it (one 32 KiB slot = 32 LDS-DMA instructions of this
+    // wave) as soon as all 8 compute waves are done with the previous occupant, and signals it the
+    // moment the data has landed -- no loader ever waits on another slot's consumers.
+    const int lw = wave - 8;
+    // chunk q = lane + 64 i of an operand image (1024 chunks): row = (lane >> 2) + 16 i, physical chunk
+    // lane & 3, and the swizzle term (-(row >> 2)) & 3 = (-(lane >> 4)) & 3 does not depend on i
+    const int row0 = lane >> 2;
+    const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+    const char* srcW = (const char*)P.W + ((long long)(n0 + row0) * K + c * 8) * 2;
+    const long long strideW = (long long)16 * K * 2;
+    const char* srcX[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = min(m0 + row0 + 16 * i, M - 1);
+      srcX[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
+    }
+    for (int t = lw; t < nslots; t += NS) {
+      const int use = t / NS;
+      if (use > 0 && ok) ok = spin_ge(done + lw, 8u * use);  // after a give-up: run through, never wait again
+      asm volatile("" ::: "memory");
+      char* base = smem + lw * SLOT;
+      const long long koff = (long long)t * SROW;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) glds16(srcW + i * strideW + koff, base + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) glds16(srcX[i] + koff, base + TN * SROW + i * 1024);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(const_cast<unsigned*>(full) + lw, 1u);
+    }
+  } else {
+    // --------------------------------- compute waves ---------------------------------
+    const int wn0 = (wave / WGM) * WTN;
+    const int wm0 = (wave % WGM) * WTM;
+    const int foff = (lane & 15) * SROW + ((((lane >> 4)) ^ ((-((lane & 15) >> 2)) & 3)) << 4);
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned seen = full[0];
+    for (int t = 0; t < nslots; ++t) {
+      const int s = t & (NS - 1), use = t / NS;
+      if (seen < (unsigned)(use + 1) && ok) ok = spin_ge(full + s, (unsigned)(use + 1));
+      asm volatile("" ::: "memory");
+      if (t + 1 < nslots) seen = full[(t + 1) & (NS - 1)];  // early poll for the next slot
+      const char* wb = smem + s * SLOT + wn0 * SROW + foff;
+      const char* xb = smem + s * SLOT + TN * SROW + wm0 * SROW + foff;
+      typename Vec8<T>::type b[FM];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) b[j] = lds_read8<T>(xb + j * 16 * SROW);
+      typename Vec8<T>::type a_cur = lds_read8<T>(wb);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        typename Vec8<T>::type a_nxt = a_cur;
+        if (i + 1 < FN) a_nxt = lds_read8<T>(wb + (i + 1) * 16 * SROW);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a_cur, b[j], acc[i][j]);
+        a_cur = a_nxt;
+      }
+      asm volatile("" ::: "memory");  // the slot's reads are all consumed by MFMAs issued above
+      if (lane == 0) atomicAdd(const_cast<unsigned*>(done) + s, 1u);
+    }
+    if (!ok && args.dbg && lane == 0) args.dbg[0] = 1;
+    __syncthreads();  // pairs with the loaders' barrier below: every slot read is over
+    if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+      epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+    } else {
+      epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
+    }
+    return;
+  }
+  if (!ok && args.dbg && lane == 0) args.dbg[0] = 1;
+  __syncthreads();
+  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) __syncthreads();  // the one inside epilogue_lds16
+}
+
 int g_force_cfg = -1;
 int g_variant = 5;  // 5 (default) = warp-specialised 256x256 + two-buffer loop for the small tiles;
                     // 0 = ring, 1 = two-buffer loop, 2 = + L2 prefetch, 3 = + spread DMA issue, 4 = stamped (diagnostic)
 unsigned long long* g_dbg = nullptr;
 
+// hipFuncSetAttribute once per kernel and device (it is not a stream operation: keep it out of the
+// per-launch path and out of graph captures)
+bool ensure_lds(const void* fn, size_t lds) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  done.insert({fn, dev});
+  return true;
+}
+
 template <typename KFN>
 int launch_k(KFN kfn, const GemmArgs& a, int threads, size_t lds, hipStream_t stream) {
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
-  }
+  if (lds > 64 * 1024 && !ensure_lds((const void*)kfn, lds)) return -3;
   hipLaunchKernelGGL(kfn, dim3(a.total_tiles), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
@@ -607,6 +757,12 @@ template <typename T>
 int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
   constexpr size_t lds = 2 * (256 + 256) * 128;
   MRA_EPI_SWITCH((launch_k(gemm_ws_kernel<T, E>, a, 768, lds, stream)))
+}
+
+template <typename T>
+int launch_ws2(const GemmArgs& a, int epi, hipStream_t stream) {
+  constexpr size_t lds = 4 * (256 + 256) * 64 + 64;
+  MRA_EPI_SWITCH((launch_k(gemm_ws2_kernel<T, E>, a, 768, lds, stream)))
 }
 
 template <typename T, int TN, int TM, int WGN, int WGM>
@@ -636,7 +792,9 @@ int launch_ring(const GemmArgs& a, int epi, hipStream_t stream) {
 
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
+  if (g_variant == 7 && cfg == 2) return launch_ws2<T>(a, epi, stream);
   if (g_variant == 5 && cfg == 2) return launch_ws<T>(a, epi, stream);
+  if (g_variant == 6 && cfg == 2 && epi == EPI_KV) return launch_k(gemm_ws_kernel<T, EPI_KV, true>, a, 768, 2 * 512 * 128, stream);
   if (g_variant == 4) return launch_v1stamp<T, 256, 256, 2, 4>(a, epi, stream);
   if (g_variant == 3) {
     if (cfg == 2) return launch_v1spread<T, 256, 256, 2, 4>(a, epi, stream);
@@ -648,7 +806,7 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
     if (cfg == 1) return launch_v1pf<T, 128, 128, 2, 2>(a, epi, stream);
     return launch_v1pf<T, 64, 64, 2, 2>(a, epi, stream);
   }
-  if (g_variant == 1 || g_variant == 5) {
+  if (g_variant == 1 || g_variant == 5 || g_variant == 7) {
     if (cfg == 2) return launch_v1<T, 256, 256, 2, 4>(a, epi, stream);
     if (cfg == 1) return launch_v1<T, 128, 128, 2, 2>(a, epi, stream);
     return launch_v1<T, 64, 64, 2, 2>(a, epi, stream);

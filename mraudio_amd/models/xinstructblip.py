@@ -116,7 +116,7 @@ class XInstructBLIP(nn.Module):
                  audio_encoder: Optional[nn.Module] = None, tokenizer=None, seed: Optional[int] = 0,
                  perturb: bool = False, op_dtype: torch.dtype = torch.float16, device=None,
                  compat_repeat: bool = True, score_alpha: float = 0.5, fuse_weights: Optional[Sequence[float]] = None,
-                 process_group=None, qformer_overrides: Optional[dict] = None):
+                 process_group=None, qformer_overrides: Optional[dict] = None, overlap_modalities: bool = True):
         super().__init__()
         self.model_path, self.audio_path = model_path, audio_path
         self.modalities = list(modalities) if modalities is not None else ["audio", "video"]  # reference :71
@@ -127,6 +127,8 @@ class XInstructBLIP(nn.Module):
         self.score_alpha = score_alpha
         self.fuse_weights = fuse_weights
         self.process_group = process_group
+        self.overlap_modalities = overlap_modalities
+        self._streams: Dict[str, torch.cuda.Stream] = {}
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.tokenizer = tokenizer if tokenizer is not None else self.init_tokenizer(truncation_side="left")
         self.video_encoder = video_encoder
@@ -237,6 +239,11 @@ class XInstructBLIP(nn.Module):
         return [{"params": decay, "weight_decay": weight_decay, "lr_scale": lr_scale},
                 {"params": no_decay, "weight_decay": 0, "lr_scale": lr_scale}]
 
+    def _side_stream(self, modality: str) -> torch.cuda.Stream:
+        if modality not in self._streams:
+            self._streams[modality] = torch.cuda.Stream(device=self._device)
+        return self._streams[modality]
+
     def _sync(self):
         for m in self.modalities:
             qf: QFormer = getattr(self, f"{m}_Qformer")
@@ -295,23 +302,37 @@ class XInstructBLIP(nn.Module):
         ids = input_ids.to(self._device)
         tmask = text_mask.to(self._device)
         att = torch.cat([torch.ones(n_local, self.num_query_token, dtype=torch.long, device=self._device), tmask], dim=1)
-        for m in self.modalities:
-            if m not in embeds:
-                continue
+        # The modality Q-Formers are independent until the fusion: each runs on its own HIP stream so
+        # the short launches of one chain fill the gaps of the other (and of its K/V projection).
+        cur = torch.cuda.current_stream(self._device)
+        live = [m for m in self.modalities if m in embeds]
+        use_streams = self.overlap_modalities and len(live) > 1
+        for m in live:
             qf: QFormer = getattr(self, f"{m}_Qformer")
             idx = None if index is None else index.get(m)
-            enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
-            res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True)
-            z = parallel.all_gather_rows(res["query"], n, self.process_group)
-            cls = parallel.all_gather_rows(res["cls"], n, self.process_group)
-            sim, logit = scorer.cosine_scores(z, cls)
-            out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
-            if want_full:
-                out["full"][m] = parallel.all_gather_rows(res["full"], n, self.process_group)
-            if want_llm:  # reference :303-306
-                y = qf.llm_proj(z)
-                out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
-                out.setdefault("atts_llm", {})[m] = torch.ones(bs, num * self.num_query_token, dtype=torch.long, device=self._device)
+            side = self._side_stream(m) if use_streams else cur
+            if use_streams:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
+                res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True)
+                z = parallel.all_gather_rows(res["query"], n, self.process_group)
+                cls = parallel.all_gather_rows(res["cls"], n, self.process_group)
+                sim, logit = scorer.cosine_scores(z, cls)
+                out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
+                if want_full:
+                    out["full"][m] = parallel.all_gather_rows(res["full"], n, self.process_group)
+                if want_llm:  # reference :303-306
+                    y = qf.llm_proj(z)
+                    out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
+                    out.setdefault("atts_llm", {})[m] = torch.ones(bs, num * self.num_query_token, dtype=torch.long, device=self._device)
+                if use_streams:  # the results are consumed on the caller's stream
+                    for t in (enc, z, cls, sim, logit, out["full"].get(m), out.get("inputs_llm", {}).get(m), out.get("atts_llm", {}).get(m)):
+                        if t is not None:
+                            t.record_stream(cur)
+        if use_streams:
+            for m in live:
+                cur.wait_stream(self._side_stream(m))
         mods = [m for m in self.modalities if m in out["logit"]]
         if not mods:
             raise MraError("no features for any of the model's modalities")

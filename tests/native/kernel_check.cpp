@@ -513,6 +513,23 @@ int main(int argc, char** argv) {
   test_gemm(2, EPI_KV, OP_F16, 256 + 10, 512, 64, false);
   test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
   test_gemm(2, EPI_OP, OP_BF16, 300, 512, 192, false);
+  {
+    unsigned long long* dbg;
+    CK(hipMalloc((void**)&dbg, 64));
+    CK(hipMemset(dbg, 0, 64));
+    gemm_set_debug_buffer(dbg);
+    gemm_force_variant(7);                               // ws2: LDS-flag hand-off, no barrier in the K loop
+    test_gemm(2, EPI_RES_F32, OP_F16, 2 * 256 + 37, 512, 320, true, 2);
+    test_gemm(2, EPI_KV, OP_F16, 256 + 10, 512, 64, false);
+    test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
+    test_gemm(2, EPI_OP, OP_BF16, 300, 512, 192, false);
+    test_gemm(2, EPI_KV, OP_F16, 2100, 1536, 1408, false);
+    unsigned long long flag = 0;
+    CK(hipMemcpy(&flag, dbg, 8, hipMemcpyDeviceToHost));
+    report("ws2 spin give-ups (must be 0)", (double)flag, 0);
+    gemm_set_debug_buffer(nullptr);
+    (void)hipFree(dbg);
+  }
   gemm_force_variant(0);                                 // ring loop
   test_gemm(2, EPI_OP, OP_F16, 300, 512, 64, false);     // K = 64: fewer slots than the ring holds
   test_gemm(0, EPI_OP, OP_F16, 100, 128, 3072, false);   // long K on the 8-slot ring
