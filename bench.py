@@ -74,13 +74,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    if os.environ.get("BENCH_SINGLE_DEVICE"):  # rehearsal of the N > 1 path on a one-GPU box (with BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mraudio_amd import _lib
     from mraudio_amd.models.xinstructblip import ENC_WIDTH, XInstructBLIP

@@ -711,6 +711,95 @@ __global__ void __launch_bounds__(768) gemm_ws2_kernel(const GemmArgs args) {
   if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) __syncthreads();  // the one inside epilogue_lds16
 }
 
+// =================================================================================================
+// k128: two 128-deep buffers (256-byte rows) for the small projections (M <= 2048 rows)
+// =================================================================================================
+// The 64x64 / 128x128 launches of the 12-layer chain are latency-bound per K step (wait -> barrier ->
+// DMA issue -> fragment reads -> 8 MFMAs: ~1100 cycles for 128 cycles of MFMA work); halving the
+// number of steps is worth more than anything inside a step.  256-byte rows: chunk index XOR (row & 15)
+// makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots.
+template <typename T, int TN, int TM, int WGN, int WGM, int EPI>
+__global__ void __launch_bounds__(WGN* WGM * 64) gemm_k128_kernel(const GemmArgs args) {
+  constexpr int BK = 128, ROWB = BK * 2, CPR = 16;
+  constexpr int NT = WGN * WGM * 64;
+  constexpr int WTN = TN / WGN, WTM = TM / WGM;
+  constexpr int FN = WTN / 16, FM = WTM / 16;
+  constexpr int IW = TN * CPR / NT, IX = TM * CPR / NT;
+  static_assert(TN * CPR % NT == 0 && TM * CPR % NT == 0, "tile/threads mismatch");
+  constexpr int BUF = (TN + TM) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn0 = (wave / WGM) * WTN;
+  const int wm0 = (wave % WGM) * WTM;
+  int n0, m0;
+  const GemmProb& P = pick_tile<TN, TM>(args, n0, m0);
+  const int K = P.K, M = P.M;
+  const char* srcW[IW];
+  const char* srcX[IX];
+#pragma unroll
+  for (int i = 0; i < IW; ++i) {
+    const int q = tid + i * NT;
+    const int row = q >> 4, c = (q & 15) ^ (row & 15);
+    srcW[i] = (const char*)P.W + ((long long)(n0 + row) * K + c * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < IX; ++i) {
+    const int q = tid + i * NT;
+    const int row = q >> 4, c = (q & 15) ^ (row & 15);
+    const int m = min(m0 + row, M - 1);
+    srcX[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
+  }
+  const int wave_q0 = wave * 64;
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * BUF;
+    const long long koff = (long long)kt * ROWB;
+#pragma unroll
+    for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, base + (wave_q0 + i * NT) * 16);
+#pragma unroll
+    for (int i = 0; i < IX; ++i) glds16(srcX[i] + koff, base + TN * ROWB + (wave_q0 + i * NT) * 16);
+  };
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int r = lane & 15;
+    foff[ks] = r * ROWB + (((4 * ks + (lane >> 4)) ^ r) << 4);
+  }
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* wb = smem + (kt & 1) * BUF + wn0 * ROWB;
+    const char* xb = smem + (kt & 1) * BUF + TN * ROWB + wm0 * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typename Vec8<T>::type a[FN], b[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) a[i] = lds_read8<T>(wb + i * 16 * ROWB + foff[ks]);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) b[j] = lds_read8<T>(xb + j * 16 * ROWB + foff[ks]);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a[i], b[j], acc[i][j]);
+    }
+  }
+  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+    __syncthreads();
+    epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+  } else {
+    epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
+  }
+}
+
 int g_force_cfg = -1;
 int g_variant = 5;  // 5 (default) = warp-specialised 256x256 + two-buffer loop for the small tiles;
                     // 0 = ring, 1 = two-buffer loop, 2 = + L2 prefetch, 3 = + spread DMA issue, 4 = stamped (diagnostic)
@@ -759,6 +848,12 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
   MRA_EPI_SWITCH((launch_k(gemm_ws_kernel<T, E>, a, 768, lds, stream)))
 }
 
+template <typename T, int TN, int TM, int WGN, int WGM>
+int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
+  constexpr size_t lds = 2 * (TN + TM) * 256;
+  MRA_EPI_SWITCH((launch_k(gemm_k128_kernel<T, TN, TM, WGN, WGM, E>, a, WGN * WGM * 64, lds, stream)))
+}
+
 template <typename T>
 int launch_ws2(const GemmArgs& a, int epi, hipStream_t stream) {
   constexpr size_t lds = 4 * (256 + 256) * 64 + 64;
@@ -792,8 +887,20 @@ int launch_ring(const GemmArgs& a, int epi, hipStream_t stream) {
 
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
+  if (g_variant == 8 && cfg < 2) {  // A/B: 128-deep steps wherever K allows
+    bool k128 = true;
+    for (int g = 0; g < a.ngroups; ++g) k128 = k128 && a.p[g].K % 128 == 0;
+    if (k128) return cfg == 1 ? launch_k128<T, 128, 128, 2, 2>(a, epi, stream) : launch_k128<T, 64, 64, 2, 2>(a, epi, stream);
+  }
+  if (g_variant == 5 && cfg == 0) {
+    // default: 128-deep steps pay on the 64x64 tile once the K loop is long (FFN down-projection,
+    // K = 3072: 367 -> 460 TF/s); at K = 768 the launch is prologue/epilogue-bound and nothing changes
+    bool k128 = true;
+    for (int g = 0; g < a.ngroups; ++g) k128 = k128 && a.p[g].K % 128 == 0 && a.p[g].K >= 2048;
+    if (k128) return launch_k128<T, 64, 64, 2, 2>(a, epi, stream);
+  }
   if (g_variant == 7 && cfg == 2) return launch_ws2<T>(a, epi, stream);
-  if (g_variant == 5 && cfg == 2) return launch_ws<T>(a, epi, stream);
+  if ((g_variant == 5 || g_variant == 8) && cfg == 2) return launch_ws<T>(a, epi, stream);
   if (g_variant == 6 && cfg == 2 && epi == EPI_KV) return launch_k(gemm_ws_kernel<T, EPI_KV, true>, a, 768, 2 * 512 * 128, stream);
   if (g_variant == 4) return launch_v1stamp<T, 256, 256, 2, 4>(a, epi, stream);
   if (g_variant == 3) {
@@ -806,7 +913,7 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
     if (cfg == 1) return launch_v1pf<T, 128, 128, 2, 2>(a, epi, stream);
     return launch_v1pf<T, 64, 64, 2, 2>(a, epi, stream);
   }
-  if (g_variant == 1 || g_variant == 5 || g_variant == 7) {
+  if (g_variant == 1 || g_variant == 5 || g_variant == 7 || g_variant == 8) {
     if (cfg == 2) return launch_v1<T, 256, 256, 2, 4>(a, epi, stream);
     if (cfg == 1) return launch_v1<T, 128, 128, 2, 2>(a, epi, stream);
     return launch_v1<T, 64, 64, 2, 2>(a, epi, stream);

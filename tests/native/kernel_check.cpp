@@ -530,6 +530,16 @@ int main(int argc, char** argv) {
     gemm_set_debug_buffer(nullptr);
     (void)hipFree(dbg);
   }
+  gemm_force_variant(8);                                 // 128-deep K steps for the 64 / 128 tiles
+  for (int cfg = 0; cfg < 2; ++cfg) {
+    const int t = cfg == 0 ? 64 : 128;
+    test_gemm(cfg, EPI_OP, OP_F16, 2 * t + 37, 2 * t, 384, true);
+    test_gemm(cfg, EPI_GELU_OP, OP_F16, t - 5, t, 128, false, 2);
+    test_gemm(cfg, EPI_RES_F32, OP_F16, 3 * t + 1, t, 768, true, 2);
+    test_gemm(cfg, EPI_KV, OP_F16, 2 * t + 10, 256, 1408, false);
+    test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 256, true);
+    test_gemm(cfg, EPI_F32, OP_F16, t, 2 * t, 192, false);   // K % 128 != 0: falls back to the 64-deep loop
+  }
   gemm_force_variant(0);                                 // ring loop
   test_gemm(2, EPI_OP, OP_F16, 300, 512, 64, false);     // K = 64: fewer slots than the ring holds
   test_gemm(0, EPI_OP, OP_F16, 100, 128, 3072, false);   // long K on the 8-slot ring
