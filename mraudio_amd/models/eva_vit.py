@@ -1,0 +1,82 @@
+"""Stock-PyTorch EVA ViT-g/14 visual encoder (row A1 callee).
+
+The reference builds it with LAVIS ``create_eva_vit_g(224, 0, False, "fp16")``
+(``models/xinstructblip.py:658-666``) and calls it once per sampled frame (``:262-266``).  LAVIS is not
+in this image, so this is a plain ``torch.nn`` restatement of the published EVA-CLIP-g geometry as LAVIS
+instantiates it: 14x14 patches of a 224x224 frame (256 + [CLS] = 257 tokens), width 1408, 16 heads,
+MLP 6144, **39** blocks (LAVIS drops the 40th), q/v bias without k bias, pre-LN blocks, no final
+norm (the reference's separate ``video_ln`` plays that role, ``:664``).  Its arithmetic stays
+PyTorch-ROCm (``F.scaled_dot_product_attention`` + rocBLAS/hipBLASLt GEMMs): the north star names no
+ViT kernels.  It exists so that an ``evaluate.py``-shaped caller has a ``video_encoder`` and so that
+``bench.py`` can report the encode stage beside the fused path.  Random weights only (no download).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        bias = torch.cat((self.q_bias, torch.zeros_like(self.v_bias), self.v_bias))
+        qkv = F.linear(x, self.qkv.weight, bias).reshape(b, n, 3, self.heads, c // self.heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(o.transpose(1, 2).reshape(b, n, c))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim: int, heads: int, mlp: int):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.fc1 = nn.Linear(dim, mlp)
+        self.fc2 = nn.Linear(mlp, dim)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.fc2(F.gelu(self.fc1(self.norm2(x))))
+
+
+class EvaViTg(nn.Module):
+    """``encoder(frames [B, 3, 224, 224]) -> [B, 257, 1408]``; ``num_features = 1408`` (reference ``:123``)."""
+
+    def __init__(self, img_size: int = 224, patch: int = 14, dim: int = 1408, depth: int = 39, heads: int = 16, mlp: int = 6144):
+        super().__init__()
+        self.num_features = dim
+        self.patch_embed = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+        n = (img_size // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.blocks = nn.ModuleList([_Block(dim, heads, mlp) for _ in range(depth)])
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+
+    def forward(self, x):
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+    def flops_per_frame(self) -> float:
+        n, d = self.pos_embed.shape[1], self.num_features
+        mlp = self.blocks[0].fc1.out_features
+        per_block = 2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 4 * n * d * mlp
+        return float(len(self.blocks) * per_block + 2 * (n - 1) * 3 * 14 * 14 * d)
+
+
+def create_eva_vit_g(img_size=224, drop_path_rate=0.0, use_checkpoint=False, precision="fp16") -> EvaViTg:
+    """Same call shape as LAVIS' factory (the reference passes exactly these four, ``:660-662``)."""
+    m = EvaViTg(img_size=img_size)
+    return m.half() if precision == "fp16" else m

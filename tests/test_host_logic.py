@@ -103,3 +103,18 @@ def test_generated_strings_round_trip_through_the_parser():
     s = O.spans_to_text([(1, 3), (0, 0)], [[0, 2, 5, 7], [4, 6, 8, 9]])
     assert s == ["[[2, 7]]", "[[4, 4]]"]
     assert [spans.moment_str_to_list(spans.post_process(x)) for x in s] == [[[2, 7]], [[4, 4]]]
+
+
+def test_eva_vit_g_geometry_cpu():
+    """Row A1 callee: stock-PyTorch EVA ViT-g restated with the geometry LAVIS instantiates
+    (reference models/xinstructblip.py:658-666): 257 tokens x 1408, 39 blocks, 520.7 GF / frame."""
+    from mraudio_amd.models.eva_vit import EvaViTg, create_eva_vit_g
+
+    m = EvaViTg(depth=2).eval()
+    with torch.no_grad():
+        y = m(torch.randn(2, 3, 224, 224))
+    assert y.shape == (2, 257, 1408) and m.num_features == 1408
+    assert abs(EvaViTg.flops_per_frame(type("S", (), {"pos_embed": torch.zeros(1, 257, 1408), "num_features": 1408,
+                                                        "blocks": [type("B", (), {"fc1": type("F", (), {"out_features": 6144})()})()] * 39})()) / 1e9 - 520.7) < 0.1
+    import inspect
+    assert list(inspect.signature(create_eva_vit_g).parameters) == ["img_size", "drop_path_rate", "use_checkpoint", "precision"]
