@@ -1,0 +1,161 @@
+// Weight-gradient GEMM for the Q-Former backward (BASELINE config 5; not in the reference, whose
+// Q-Formers are frozen, models/xinstructblip.py:196-204):
+//     dW[n][k] (+)= sum_m dY[m][n] * X[m][k]            (nn.Linear: Y = X W^T  =>  dW = dY^T X)
+// plus the bias gradient db[n] = sum_m dY[m][n] (colsum_kernel).
+//
+// Both operands are row-major over the contraction index m, the wrong way round for an MFMA operand
+// (a lane wants 8 consecutive m of one column).  Tiles [32 m][64 cols] are staged by LDS-DMA exactly
+// like the V tile of the attention kernel (128-byte rows, 16-byte chunk index XOR ((m >> 1) & 1) << 2 on
+// the source address) and both fragments come from ds_read_b64_tr_b16 transposed reads:
+//     D[32 n x 32 k] += A[32 n x 16 m] * B[16 m x 32 k],   v_mfma_f32_32x32x16, fp32 accumulate.
+// One workgroup = 64 n x 64 k (4 waves, one 32x32 tile each), double-buffered over m.  Gradient GEMMs
+// are small here (M = items * S ~ 1 k rows): this kernel is written for correctness and decent
+// occupancy, not for the roofline.
+#include "kernels.h"
+#include "mra_common.h"
+
+namespace mra {
+
+namespace {
+
+constexpr int BMT = 32;                 // contraction rows per step
+constexpr int TILE_B = BMT * 128;       // bytes per operand tile
+
+__device__ __forceinline__ long long tn_row_off(const RowView& v, int m) {
+  const int item = m / v.rpi;
+  return (long long)item * v.item_stride + (long long)(m - item * v.rpi) * v.ld;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = blockIdx.x, kb = blockIdx.y;     // 64-column blocks of dY and of X
+  const T* Y = (const T*)a.dY + (long long)nb * a.y_block_stride;
+  const T* X = (const T*)a.X + (long long)kb * a.x_block_stride;
+  const int M = a.M;
+
+  // LDS-DMA: 256 chunks of 16 B per operand tile, one per thread: row = tid >> 3, physical chunk tid & 7
+  const int srow = tid >> 3, sc = tid & 7;
+  const int src_chunk = sc ^ (((srow >> 1) & 1) << 2);
+  auto issue = [&](int buf, int m0) {
+    const int m = min(m0 + srow, M - 1);  // rows past M are masked below by zeroing their contribution
+    char* yb = smem + buf * 2 * TILE_B;
+    glds16((const char*)(Y + tn_row_off(a.yv, m)) + src_chunk * 16, yb + wave * 1024);
+    glds16((const char*)(X + tn_row_off(a.xv, m)) + src_chunk * 16, yb + TILE_B + wave * 1024);
+  };
+  // transposed-read lane offsets (same derivation as the V operand of attention.hip): 16-lane group g,
+  // lane-in-group i = 4 q4 + p reads 8 bytes of row 4 h + q4 (+ 8 e + 16 s) at column 32 ct + 16 (g & 1) + 4 p
+  unsigned lane_off[2];
+  {
+    const int g = lane >> 4, i = lane & 15, q4 = i >> 2, p = i & 3, h = lane >> 5;
+    const int row = 4 * h + q4;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = 4 * ct + 2 * (g & 1) + (p >> 1);
+      const int pc = c ^ (((q4 >> 1) & 1) << 2);
+      lane_off[ct] = row * 128 + pc * 16 + (p & 1) * 8;
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int ct_n = wave >> 1, ct_k = wave & 1;  // this wave's 32-column halves of the n and k blocks
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nsteps = (M + BMT - 1) / BMT;
+  issue(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nsteps) issue((st + 1) & 1, (st + 1) * BMT);
+    const unsigned ybase = lds0 + (st & 1) * 2 * TILE_B + lane_off[ct_n];
+    const unsigned xbase = ybase - lane_off[ct_n] + TILE_B + lane_off[ct_k];
+    i16x4 ya0, ya1, ya2, ya3, xb0, xb1, xb2, xb3;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
+        "ds_read_b64_tr_b16 %4, %9\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(ya0), "=&v"(ya1), "=&v"(ya2), "=&v"(ya3), "=&v"(xb0), "=&v"(xb1), "=&v"(xb2), "=&v"(xb3)
+        : "v"(ybase), "v"(xbase)
+        : "memory");
+    auto cat = [](i16x4 lo, i16x4 hi) {
+      i16x8 v8;
+      v8[0] = lo[0]; v8[1] = lo[1]; v8[2] = lo[2]; v8[3] = lo[3];
+      v8[4] = hi[0]; v8[5] = hi[1]; v8[6] = hi[2]; v8[7] = hi[3];
+      return v8;
+    };
+    i16x8 A0 = cat(ya0, ya1), A1 = cat(ya2, ya3), B0 = cat(xb0, xb1), B1 = cat(xb2, xb3);
+    // rows past M: the clamped source row was loaded again; zero the A elements of those rows.
+    // Element j of the fragment of k-step s is row 16 s + 8 (j >> 2) + 4 h + (j & 3).
+    const int mrem = M - st * BMT;
+    if (mrem < BMT) {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (8 * (j >> 2) + 4 * h + (j & 3) >= mrem) A0[j] = 0;
+        if (16 + 8 * (j >> 2) + 4 * h + (j & 3) >= mrem) A1[j] = 0;
+      }
+    }
+    acc = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A0), __builtin_bit_cast(typename Vec8<T>::type, B0), acc);
+    acc = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A1), __builtin_bit_cast(typename Vec8<T>::type, B1), acc);
+  }
+  // D: column k = lane & 31, row n = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int kcol = kb * 64 + ct_k * 32 + (lane & 31);
+  float* out = a.dW + (long long)(nb * 64 + ct_n * 32) * a.ldw + kcol;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float* p = out + (long long)n * a.ldw;
+    *p = a.accumulate ? *p + acc[r] : acc[r];
+  }
+}
+
+// db[n] (+)= sum_m dY[m][n]; one wave per 64-column block, lanes = columns, 4 waves split the rows
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const void* dY_, long long block_stride, RowView yv, int M, float* db,
+                                                     int accumulate) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* Y = (const T*)dY_ + (long long)blockIdx.x * block_stride + lane;
+  float s = 0.f;
+  for (int m = wave; m < M; m += 4) s += (float)Y[tn_row_off(yv, m)];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    float* p = db + blockIdx.x * 64 + lane;
+    *p = accumulate ? *p + t : t;
+  }
+}
+
+}  // namespace
+
+int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  if (a.N % 64 || a.K % 64) return -1;
+  if (a.yv.rpi <= 0 || a.xv.rpi <= 0 || (a.yv.ld & 7) || (a.xv.ld & 7)) return -1;
+  const dim3 grid(a.N / 64, a.K / 64), block(256);
+  const size_t lds = 4 * TILE_B;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, lds, stream, a);
+  else hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_colsum(const void* dY, long long block_stride, RowView yv, int M, int N, float* db, int accumulate, int op_dtype,
+                  hipStream_t stream) {
+  if (M <= 0 || N <= 0 || N % 64 || yv.rpi <= 0) return -1;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(colsum_kernel<f16>, dim3(N / 64), dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
+  else hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(N / 64), dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace mra

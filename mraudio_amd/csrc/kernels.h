@@ -58,6 +58,25 @@ void gemm_set_debug_buffer(unsigned long long* dev_buf);  // variant 4 (stamped 
 void gemm_force_variant(int v);   // 5 = default (warp-specialised 256x256, two-buffer small tiles); 0 ring, 1 two-buffer,
                                   // 2 +L2 prefetch, 3 +spread DMA issue, 4 stamped diagnostic -- kept for A/B runs
 
+// ---- backward-pass GEMMs ------------------------------------------------------------------------
+// dW[n][k] (+)= sum_m dY[m][n] * X[m][k].  dY and X are given as 64-column blocks: block b of dY starts at
+// dY + b * y_block_stride and its row m at + row-view(yv, m) (row-major [M, N]: block stride 64, ld N;
+// head-major K/V gradients: block = (layer, k|v, head), stride kv * 64, item stride heads * kv * 64, ld 64).
+struct GemmTnArgs {
+  const void* dY;
+  const void* X;
+  float* dW;   // [N][ldw] f32
+  RowView yv, xv;
+  long long y_block_stride, x_block_stride;
+  int M, N, K;
+  int ldw;
+  int accumulate;  // 1: dW += ...
+};
+int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream);
+// db[n] (+)= sum_m dY[m][n]
+int launch_colsum(const void* dY, long long block_stride, RowView yv, int M, int N, float* db, int accumulate, int op_dtype,
+                  hipStream_t stream);
+
 // ---- attention ------------------------------------------------------------------------------
 struct AttnArgs {
   const void* Q;  // [item][q row][head*64 + d], op dtype

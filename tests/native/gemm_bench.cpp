@@ -85,10 +85,10 @@ int main(int argc, char** argv) {
     p.M = s.M; p.N = s.N; p.K = s.K;
     if (s.epi == EPI_KV) { p.kv_tokens = s.M / 32; p.kv_items = 32; p.kv_heads = 12; }
     gemm_force_config(s.cfg);
-    double best[9] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
+    double best[10] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
     const int reps = s.M > 100000 ? 3 : 20;
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 9; ++v) {
+      for (int v = 0; v < 10; ++v) {
         if (v == 4 || (v == 6 && s.epi != EPI_KV)) continue;
         if (only_variant >= 0 && v != only_variant) continue;
         gemm_force_variant(v);
@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
       }
     const double fl = 2.0 * s.M * s.N * s.K;
     printf("%-36s %10.1f %10.1f %10.1f %10.1f %10.1f %8.1f\n", s.name, fl / best[0] / 1e9, fl / best[1] / 1e9, fl / best[2] / 1e9, fl / best[3] / 1e9, fl / best[5] / 1e9, best[1] * 1e3);
-    printf("    ws2 (flag hand-off, no K-loop barrier): %.1f TF/s   k128 small tiles: %.1f TF/s (%.1f us)\n", fl / best[7] / 1e9, fl / best[8] / 1e9, best[8] * 1e3);
+    printf("    ws2 (flag hand-off, no K-loop barrier): %.1f TF/s   k128 small tiles: %.1f TF/s (%.1f us)   rot: %.1f TF/s\n", fl / best[7] / 1e9, fl / best[8] / 1e9, best[8] * 1e3, fl / best[9] / 1e9);
     if (s.epi == EPI_KV) printf("    (diagnostic, wrong results) ws without DMA after tile 1: %.1f TF/s\n", fl / best[6] / 1e9);
     fflush(stdout);
   }

@@ -308,6 +308,60 @@ static void test_attention(int op, int items, int heads, int q_rows, int kv_len,
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight-gradient GEMM dW = dY^T X (+ bias gradient), row-major and head-major dY, ragged M, accumulate
+static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accumulate) {
+  const int kv = 37;                           // head-major: rows = items * kv tokens, blocks of 64 cols = "heads"
+  const int items = headmajor ? (M + kv - 1) / kv : 1;
+  if (headmajor) M = items * kv;
+  std::vector<uint16_t> Y((size_t)M * N), X((size_t)M * K);
+  std::vector<float> Yf(Y.size()), Xf(X.size());
+  for (size_t i = 0; i < Y.size(); ++i) { Y[i] = to_op(frand(), op); Yf[i] = from_op(Y[i], op); }
+  for (size_t i = 0; i < X.size(); ++i) { X[i] = to_op(frand(), op); Xf[i] = from_op(X[i], op); }
+  // device layout of dY
+  std::vector<uint16_t> Yd(Y.size());
+  const int nblocks = N / 64;
+  if (headmajor) {
+    for (int it = 0; it < items; ++it)
+      for (int b = 0; b < nblocks; ++b)
+        for (int t = 0; t < kv; ++t)
+          for (int d = 0; d < 64; ++d) Yd[(((size_t)it * nblocks + b) * kv + t) * 64 + d] = Y[(size_t)(it * kv + t) * N + b * 64 + d];
+  } else {
+    Yd = Y;
+  }
+  std::vector<float> W0((size_t)N * K), B0(N);
+  for (auto& v : W0) v = frand();
+  for (auto& v : B0) v = frand();
+  Dev<uint16_t> dY(Yd), dX(X);
+  Dev<float> dW(W0), dB(B0);
+  GemmTnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dY = dY.p; a.X = dX.p; a.dW = dW.p;
+  a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = accumulate;
+  a.xv = RowView{0, M, K}; a.x_block_stride = 64;
+  if (headmajor) { a.yv = RowView{(long long)nblocks * kv * 64, kv, 64}; a.y_block_stride = (long long)kv * 64; }
+  else { a.yv = RowView{0, M, N}; a.y_block_stride = 64; }
+  int rc = launch_gemm_tn(a, op, 0);
+  rc |= launch_colsum(dY.p, a.y_block_stride, a.yv, M, N, dB.p, accumulate, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> W = dW.get(), B = dB.get();
+  double worst = rc ? 1e30 : 0, worstb = rc ? 1e30 : 0;
+  for (int n = 0; n < N && !rc; ++n) {
+    double bs = accumulate ? B0[n] : 0;
+    for (int m = 0; m < M; ++m) bs += Yf[(size_t)m * N + n];
+    worstb = std::max(worstb, fabs(bs - B[n]) / (1 + fabs(bs)));
+    for (int k = 0; k < K; ++k) {
+      double acc = accumulate ? W0[(size_t)n * K + k] : 0;
+      for (int m = 0; m < M; ++m) acc += (double)Yf[(size_t)m * N + n] * Xf[(size_t)m * K + k];
+      worst = std::max(worst, fabs(acc - W[(size_t)n * K + k]) / (1 + fabs(acc)));
+    }
+  }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm_tn %s M%d N%d K%d %s%s", op == OP_F16 ? "f16" : "bf16", M, N, K, headmajor ? "head-major" : "row-major", accumulate ? " +=" : "");
+  report(name, worst, 2e-5);
+  report(std::string(name) + " colsum", worstb, 2e-5);
+}
+
+// ------------------------------------------------------------------------------------------------
 static void test_ln_rows(int op) {
   const int items = 5, S = 9, H = 768, rpi = 4, off = 2;
   std::vector<float> x((size_t)items * S * H), g(H), b(H);
@@ -470,6 +524,10 @@ int main(int argc, char** argv) {
   CK(hipGetDeviceProperties(&prop, dev));
   printf("device: %s (%s), %d CUs\n", prop.name, prop.gcnArchName, prop.multiProcessorCount);
 
+  test_gemm_tn(OP_F16, 100, 64, 64, false, false);
+  test_gemm_tn(OP_F16, 1040, 128, 192, false, true);
+  test_gemm_tn(OP_BF16, 333, 192, 128, false, false);
+  test_gemm_tn(OP_F16, 300, 128, 64, true, true);
   test_ln_rows(OP_F16);
   test_ln_rows(OP_BF16);
   test_modality_ln(0, 1408);
@@ -530,6 +588,11 @@ int main(int argc, char** argv) {
     gemm_set_debug_buffer(nullptr);
     (void)hipFree(dbg);
   }
+  gemm_force_variant(9);                                 // rot: deferred half tile across the barrier
+  test_gemm(2, EPI_RES_F32, OP_F16, 2 * 256 + 37, 512, 320, true, 2);
+  test_gemm(2, EPI_KV, OP_F16, 256 + 10, 512, 64, false);
+  test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
+  test_gemm(2, EPI_OP, OP_BF16, 300, 512, 128, false);
   gemm_force_variant(8);                                 // 128-deep K steps for the 64 / 128 tiles
   for (int cfg = 0; cfg < 2; ++cfg) {
     const int t = cfg == 0 ? 64 : 128;
