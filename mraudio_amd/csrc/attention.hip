@@ -281,6 +281,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
       for (int e = 0; e < 4; ++e) { o[e] += wgt * x0[e]; o[4 + e] += wgt * x1[e]; }
     }
     if (!active) continue;
+    if (a.lse && a.nsplit == 1 && dc == 0 && q0 + q < a.q_rows)
+      a.lse[((long long)item * a.heads + head) * a.q_rows + q0 + q] = M + __builtin_amdgcn_logf(L);  // v_log_f32 = log2
     if (a.nsplit > 1) {
       float* pp = a.part + ((long long)unit * a.nsplit + gs) * PART_STRIDE;
       *reinterpret_cast<f32x4*>(pp + q * 64 + 8 * dc) = f32x4{o[0], o[1], o[2], o[3]};
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnArgs a) {
   }
   const int q0 = qb * 32;
   if (q0 + q >= a.q_rows) return;
+  if (a.lse && dc == 0) a.lse[((long long)item * a.heads + head) * a.q_rows + q0 + q] = M + __builtin_amdgcn_logf(L);
   const float inv = 1.0f / L;
   typename Vec8<T>::type r;
 #pragma unroll

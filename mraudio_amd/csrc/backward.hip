@@ -1,0 +1,373 @@
+// Backward-pass kernels of the Q-Former (BASELINE config 5: "Q-Former fwd+bwd with fused LN/GELU grads").
+// The reference never back-propagates through its Q-Formers (they are frozen,
+// models/xinstructblip.py:196-204); the definition of "right" here is torch.autograd over the CPU oracle
+// (tests/test_gpu_backward.py).  Sizes are a fine-tuning batch (items * S ~ 1 k rows), so these kernels
+// favour simplicity; the two weight-gradient / data-gradient GEMMs (gemm_tn.hip, gemm.hip) carry the flops.
+//
+//   ln_bwd_kernel        dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma, statistics
+//                        recomputed from the saved pre-LN row; dgamma / dbeta by per-workgroup partial sums
+//                        in registers + LDS, then one float atomic per column and workgroup.
+//   gelu_fwd / gelu_bwd  exact (erf) GELU and its derivative, elementwise on the up-projection.
+//   attn_bwd_kernel      flash-style recompute from (Q, K, V, O, dO, LSE): one workgroup per (item, head),
+//                        KV tiles outer / 32-row query blocks inner, dK/dV of a tile and dQ of the whole
+//                        head accumulate in LDS (fp32): no atomics, reproducible.  fp32 VALU math.
+//   embed_bwd_kernel     gradients of query tokens, position and word embeddings (row atomics for words).
+//   transpose16_kernel   W [R][C] -> W^T [C][R] (operand dtype) for the data-gradient GEMMs.
+#include "kernels.h"
+#include "mra_common.h"
+
+namespace mra {
+
+namespace {
+
+__device__ __forceinline__ long long brow(const RowView& v, int m) {
+  const int item = m / v.rpi;
+  return (long long)item * v.item_stride + (long long)(m - item * v.rpi) * v.ld;
+}
+
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v) {
+  typename Vec4<T>::type o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+  *reinterpret_cast<typename Vec4<T>::type*>(p) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  H = 256 * NV.  RPW rows per wave, 4 waves per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
+  constexpr int H = NV * 256, RPW = 4;
+  __shared__ float red[2][4][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; }
+  f32x4 gam[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) gam[i] = *reinterpret_cast<const f32x4*>(a.gamma + (i * 64 + lane) * 4);
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = (blockIdx.x * 4 + wave) * RPW + rr;
+    if (row >= a.rows) break;
+    const float* xr = a.x + brow(a.xv, row);
+    const float* dyr = a.dy + brow(a.dyv, row);
+    f32x4 x[NV], dy[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      x[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+      dy[i] = *reinterpret_cast<const f32x4*>(dyr + (i * 64 + lane) * 4);
+      s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[i][e] -= mean; q += x[i][e] * x[i][e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + a.eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[i][e] *= rstd;  // xhat
+        const float g = dy[i][e] * gam[i][e];
+        sg += g;
+        sgx += g * x[i][e];
+        dg[i][e] += dy[i][e] * x[i][e];
+        db[i][e] += dy[i][e];
+      }
+    sg = wave_sum(sg) * (1.0f / H);
+    sgx = wave_sum(sgx) * (1.0f / H);
+    float* dxr = a.dx + brow(a.dxv, row);
+    const float* addr = a.add ? a.add + brow(a.addv, row) : nullptr;
+    T* dx16 = a.dx16 ? (T*)a.dx16 + brow(a.dx16v, row) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = rstd * (dy[i][e] * gam[i][e] - sg - x[i][e] * sgx);
+      if (addr) d += *reinterpret_cast<const f32x4*>(addr + c);
+      *reinterpret_cast<f32x4*>(dxr + c) = d;
+      if (dx16) st4<T>(dx16 + c, d);
+    }
+  }
+  if (!a.dgamma) return;
+  // workgroup reduction of the parameter gradients, then one atomic per column
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    *reinterpret_cast<f32x4*>(&red[0][wave][(i * 64 + lane) * 4]) = dg[i];
+    *reinterpret_cast<f32x4*>(&red[1][wave][(i * 64 + lane) * 4]) = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(a.dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+    atomicAdd(a.dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GELU
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  return cdf + u * 0.39894228040143267794f * __expf(-0.5f * u * u);
+}
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) gelu_kernel(const T* u, const T* df, T* out, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const typename Vec8<T>::type uv = *reinterpret_cast<const typename Vec8<T>::type*>(u + i * 8);
+    typename Vec8<T>::type o;
+    if (BWD) {
+      const typename Vec8<T>::type dv = *reinterpret_cast<const typename Vec8<T>::type*>(df + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>((float)dv[e] * gelu_grad((float)uv[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(gelu_erf((float)uv[e]));
+    }
+    *reinterpret_cast<typename Vec8<T>::type*>(out + i * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention backward
+// ---------------------------------------------------------------------------------------------
+constexpr int QB = 32, KB = 32, DH = 64, PADW = 65;  // block sizes; LDS rows padded to 65 floats
+constexpr float LOG2E_B = 1.4426950408889634f;
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % a.heads, item = blockIdx.x / a.heads;
+  const int nqb = (a.q_rows + QB - 1) / QB, nkb = (a.kv_len + KB - 1) / KB;
+  float* dQs = smem;                       // [nqb*QB][PADW]
+  float* Qs = dQs + nqb * QB * PADW;       // [QB][PADW]
+  float* dOs = Qs + QB * PADW;
+  float* Ks = dOs + QB * PADW;             // [KB][PADW]
+  float* Vs = Ks + KB * PADW;
+  float* dKs = Vs + KB * PADW;
+  float* dVs = dKs + KB * PADW;
+  float* Ps = dVs + KB * PADW;             // [QB][KB + 1]
+  float* dSs = Ps + QB * (KB + 1);
+  float* delta = dSs + QB * (KB + 1);      // [nqb*QB]
+  float* lse = delta + nqb * QB;           // [nqb*QB]
+
+  const T* Qg = (const T*)a.Q + (long long)item * a.q_item_stride + head * DH;
+  const T* dOg = (const T*)a.dO + (long long)item * a.o_item_stride + head * DH;
+  const T* Og = (const T*)a.O + (long long)item * a.o_item_stride + head * DH;
+  const T* Kg = (const T*)a.K + (long long)item * a.k_item_stride + (long long)head * a.k_head_stride;
+  const T* Vg = (const T*)a.V + (long long)item * a.v_item_stride + (long long)head * a.v_head_stride;
+  T* dQg = (T*)a.dQ + (long long)item * a.dq_item_stride + head * DH;
+  T* dKg = (T*)a.dK + (long long)item * a.dk_item_stride + (long long)head * a.dk_head_stride;
+  T* dVg = (T*)a.dV + (long long)item * a.dv_item_stride + (long long)head * a.dv_head_stride;
+
+  for (int i = tid; i < nqb * QB * PADW; i += 256) dQs[i] = 0.f;
+  // delta[q] = sum_d dO[q][d] * O[q][d]; lse from the forward (log2 units, mask included)
+  for (int q = tid; q < nqb * QB; q += 256) {
+    float s = 0.f;
+    if (q < a.q_rows) {
+      for (int d = 0; d < DH; ++d) s += (float)dOg[(long long)q * a.o_ld + d] * (float)Og[(long long)q * a.o_ld + d];
+      lse[q] = a.lse[((long long)item * a.heads + head) * a.q_rows + q];
+    } else {
+      lse[q] = 0.f;
+    }
+    delta[q] = s;
+  }
+  __syncthreads();
+  const float sl2 = a.scale * LOG2E_B;
+  for (int kb = 0; kb < nkb; ++kb) {
+    // K / V tile (rows past kv_len zero), dK / dV accumulators
+    for (int i = tid; i < KB * DH; i += 256) {
+      const int t = i >> 6, d = i & 63, tok = kb * KB + t;
+      float kv = 0.f, vv = 0.f;
+      if (tok < a.kv_len) { kv = (float)Kg[(long long)tok * a.k_ld + d]; vv = (float)Vg[(long long)tok * a.v_ld + d]; }
+      Ks[t * PADW + d] = kv; Vs[t * PADW + d] = vv;
+      dKs[t * PADW + d] = 0.f; dVs[t * PADW + d] = 0.f;
+    }
+    for (int qb = 0; qb < nqb; ++qb) {
+      __syncthreads();
+      for (int i = tid; i < QB * DH; i += 256) {
+        const int q = i >> 6, d = i & 63, qr = qb * QB + q;
+        float qv = 0.f, dv = 0.f;
+        if (qr < a.q_rows) { qv = (float)Qg[(long long)qr * a.q_ld + d]; dv = (float)dOg[(long long)qr * a.o_ld + d]; }
+        Qs[q * PADW + d] = qv; dOs[q * PADW + d] = dv;
+      }
+      __syncthreads();
+      // P and dS: 1024 (q, t) pairs, 4 per thread
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = tid + r * 256, q = idx >> 5, t = idx & 31;
+        const int qr = qb * QB + q, tok = kb * KB + t;
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < DH; ++d) {
+          s += Qs[q * PADW + d] * Ks[t * PADW + d];
+          dp += dOs[q * PADW + d] * Vs[t * PADW + d];
+        }
+        float p = 0.f;
+        if (qr < a.q_rows && tok < a.kv_len) {
+          float y = s * sl2;
+          if (a.mask) y += (1.0f - (float)a.mask[(long long)item * a.mask_ld + tok]) * (-10000.0f * LOG2E_B);
+          p = __builtin_amdgcn_exp2f(y - lse[qr]);
+        }
+        Ps[q * (KB + 1) + t] = p;
+        dSs[q * (KB + 1) + t] = p * (dp - delta[qr]) * a.scale;
+      }
+      __syncthreads();
+      // dV[t][d] += sum_q P[q][t] dO[q][d];  dK[t][d] += sum_q dS[q][t] Q[q][d]   (2048 outputs, 8 per thread)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int idx = tid + r * 256, t = idx >> 6, d = idx & 63;
+        float av = 0.f, ak = 0.f;
+        for (int q = 0; q < QB; ++q) {
+          av += Ps[q * (KB + 1) + t] * dOs[q * PADW + d];
+          ak += dSs[q * (KB + 1) + t] * Qs[q * PADW + d];
+        }
+        dVs[t * PADW + d] += av;
+        dKs[t * PADW + d] += ak;
+      }
+      // dQ[q][d] += sum_t dS[q][t] K[t][d]
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int idx = tid + r * 256, q = idx >> 6, d = idx & 63;
+        float aq = 0.f;
+        for (int t = 0; t < KB; ++t) aq += dSs[q * (KB + 1) + t] * Ks[t * PADW + d];
+        dQs[(qb * QB + q) * PADW + d] += aq;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < KB * DH; i += 256) {
+      const int t = i >> 6, d = i & 63, tok = kb * KB + t;
+      if (tok < a.kv_len) {
+        dKg[(long long)tok * a.dk_ld + d] = from_f32<T>(dKs[t * PADW + d]);
+        dVg[(long long)tok * a.dv_ld + d] = from_f32<T>(dVs[t * PADW + d]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nqb * QB * DH; i += 256) {
+    const int q = i >> 6, d = i & 63;
+    if (q < a.q_rows) dQg[(long long)q * a.dq_ld + d] = from_f32<T>(dQs[q * PADW + d]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embeddings backward: d_emb [items][Q + L][H] f32
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const float* demb, const long long* ids, int items, int L, int Q, int H,
+                                                        int vocab, float* dquery, float* dpos, float* dword) {
+  // one workgroup per sequence position s; threads over columns; loop over items
+  const int s = blockIdx.x, S = Q + L;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < items; ++n) {
+      const float g = demb[((long long)n * S + s) * H + c];
+      acc += g;
+      if (s >= Q && dword) {
+        long long id = ids[(long long)n * L + (s - Q)];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        atomicAdd(dword + id * H + c, g);
+      }
+    }
+    if (s < Q) { if (dquery) dquery[(long long)s * H + c] += acc; }
+    else if (dpos) dpos[(long long)(s - Q) * H + c] += acc;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) transpose16_kernel(const T* src, T* dst, int R, int C) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < R && bx + tx < C) tile[j][tx] = src[(long long)(by + j) * C + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < C && by + tx < R) dst[(long long)(bx + j) * R + by + tx] = tile[tx][j];
+}
+
+__global__ void __launch_bounds__(256) axpy_kernel(const float* x, float* y, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4), b = *reinterpret_cast<f32x4*>(y + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = a + b;
+  }
+}
+
+}  // namespace
+
+int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream) {
+  if (a.rows <= 0) return 0;
+  if (H % 256 || H > 1024 || H <= 0) return -1;
+  const dim3 grid((a.rows + 15) / 16), block(256);
+#define MRA_LNB(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, stream, a)
+  const int nv = H / 256;
+  if (op_dtype == OP_F16) {
+    if (nv == 1) MRA_LNB(f16, 1); else if (nv == 2) MRA_LNB(f16, 2); else if (nv == 3) MRA_LNB(f16, 3); else MRA_LNB(f16, 4);
+  } else {
+    if (nv == 1) MRA_LNB(bf16, 1); else if (nv == 2) MRA_LNB(bf16, 2); else if (nv == 3) MRA_LNB(bf16, 3); else MRA_LNB(bf16, 4);
+  }
+#undef MRA_LNB
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_gelu(const void* u, const void* df, void* out, long long n, int backward, int op_dtype, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n % 8) return -1;
+  const long long n8 = n / 8;
+  const unsigned blocks = (unsigned)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  if (op_dtype == OP_F16) {
+    if (backward) hipLaunchKernelGGL((gelu_kernel<f16, true>), dim3(blocks), dim3(256), 0, stream, (const f16*)u, (const f16*)df, (f16*)out, n8);
+    else hipLaunchKernelGGL((gelu_kernel<f16, false>), dim3(blocks), dim3(256), 0, stream, (const f16*)u, (const f16*)df, (f16*)out, n8);
+  } else {
+    if (backward) hipLaunchKernelGGL((gelu_kernel<bf16, true>), dim3(blocks), dim3(256), 0, stream, (const bf16*)u, (const bf16*)df, (bf16*)out, n8);
+    else hipLaunchKernelGGL((gelu_kernel<bf16, false>), dim3(blocks), dim3(256), 0, stream, (const bf16*)u, (const bf16*)df, (bf16*)out, n8);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+size_t attn_bwd_lds_bytes(int q_rows) {
+  const int nqb = (q_rows + QB - 1) / QB;
+  return sizeof(float) * ((size_t)nqb * QB * PADW + 2 * QB * PADW + 4 * KB * PADW + 2 * QB * (KB + 1) + 2 * nqb * QB);
+}
+
+int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream) {
+  if (a.items <= 0 || a.heads <= 0 || a.q_rows <= 0 || a.kv_len <= 0 || !a.lse) return -1;
+  const size_t lds = attn_bwd_lds_bytes(a.q_rows);
+  if (lds > 160 * 1024) return -1;
+  void (*kfn)(const AttnBwdArgs) = op_dtype == OP_F16 ? attn_bwd_kernel<f16> : attn_bwd_kernel<bf16>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+  hipLaunchKernelGGL(kfn, dim3(a.items * a.heads), dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, int Q, int H, int vocab, float* dquery, float* dpos,
+                     float* dword, hipStream_t stream) {
+  if (items <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(Q + L), dim3(256), 0, stream, demb, ids, items, L, Q, H, vocab, dquery, dpos, dword);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return -1;
+  const dim3 grid((C + 31) / 32, (R + 31) / 32), block(256);
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(transpose16_kernel<f16>, grid, block, 0, stream, (const f16*)src, (f16*)dst, R, C);
+  else hipLaunchKernelGGL(transpose16_kernel<bf16>, grid, block, 0, stream, (const bf16*)src, (bf16*)dst, R, C);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n % 4) return -1;
+  const long long n4 = n / 4;
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, stream, x, y, n4);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace mra

@@ -77,6 +77,41 @@ int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream);
 int launch_colsum(const void* dY, long long block_stride, RowView yv, int M, int N, float* db, int accumulate, int op_dtype,
                   hipStream_t stream);
 
+// ---- backward-pass row / elementwise / attention kernels (backward.hip) ----------------------------
+struct LnBwdArgs {
+  const float* dy; RowView dyv;   // upstream gradient of the LayerNorm output
+  const float* x; RowView xv;     // saved pre-LN rows (statistics are recomputed)
+  const float* gamma;
+  float eps;
+  int rows;
+  float* dx; RowView dxv;         // gradient w.r.t. the pre-LN rows (+ `add` when given)
+  const float* add; RowView addv; // optional second gradient stream added into dx (the residual branch)
+  void* dx16; RowView dx16v;      // optional operand-dtype copy of dx
+  float* dgamma; float* dbeta;    // optional, accumulated with float atomics
+};
+int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream);
+// out = gelu_erf(u) (backward = 0) or out = df * gelu'(u) (backward = 1); operand dtype, n % 8 == 0
+int launch_gelu(const void* u, const void* df, void* out, long long n, int backward, int op_dtype, hipStream_t stream);
+struct AttnBwdArgs {
+  const void *Q, *K, *V, *O, *dO;   // operand dtype; O / dO share the [item][q row][head*64 + d] layout
+  void *dQ, *dK, *dV;               // operand dtype; same layouts as Q / K / V (own strides)
+  long long q_item_stride, o_item_stride, dq_item_stride;
+  int q_ld, o_ld, dq_ld;
+  long long k_item_stride, k_head_stride, v_item_stride, v_head_stride;
+  int k_ld, v_ld;
+  long long dk_item_stride, dk_head_stride, dv_item_stride, dv_head_stride;
+  int dk_ld, dv_ld;
+  const long long* mask; int mask_ld;
+  const float* lse;                 // [item][head][q_rows] from the forward
+  int items, heads, q_rows, kv_len;
+  float scale;
+};
+int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream);
+int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, int Q, int H, int vocab, float* dquery, float* dpos,
+                     float* dword, hipStream_t stream);
+int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, hipStream_t stream);
+int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream);  // y += x
+
 // ---- attention ------------------------------------------------------------------------------
 struct AttnArgs {
   const void* Q;  // [item][q row][head*64 + d], op dtype
@@ -95,6 +130,7 @@ struct AttnArgs {
   // grid-level KV split (cross attention with long KV): partials in `part`, combined by a 2nd kernel
   int nsplit;
   float* part;   // [items*heads*qblocks][nsplit][32*64 + 64] f32
+  float* lse;    // optional [item][head][q_rows] f32: log2-sum-exp2 of the scaled, masked scores (for the backward)
 };
 size_t attn_partial_bytes(int items, int heads, int q_rows, int nsplit);
 int attn_pick_split(int items, int heads, int q_rows, int kv_len);

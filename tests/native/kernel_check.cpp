@@ -516,6 +516,218 @@ static void test_score() {
   report("span_from_logits (integer mismatches)", bad, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward kernels (config 5) against double-precision host loops
+static void test_ln_bwd() {
+  const int items = 5, S = 9, H = 768, rpi = 4, off = 2, rows = items * rpi;
+  std::vector<float> x((size_t)items * S * H), dy((size_t)rows * H), add((size_t)rows * H), g(H);
+  for (auto& v : x) v = frand(2.f) + 0.3f;
+  for (auto& v : dy) v = frand();
+  for (auto& v : add) v = frand();
+  for (auto& v : g) v = 1.f + frand(0.2f);
+  std::vector<float> dg0(H), db0(H);
+  for (auto& v : dg0) v = frand();
+  for (auto& v : db0) v = frand();
+  Dev<float> dx_(x), ddy(dy), dadd(add), dgam(g), dout((size_t)items * S * H), ddg(dg0), ddb(db0);
+  Dev<uint16_t> d16((size_t)rows * H);
+  dout.fill(0);
+  LnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  const RowView v{(long long)S * H, rpi, H}, c{0, rows, H};
+  a.dy = ddy.p; a.dyv = c; a.x = dx_.p + off * H; a.xv = v; a.gamma = dgam.p; a.eps = 1e-12f; a.rows = rows;
+  a.dx = dout.p + off * H; a.dxv = v; a.add = dadd.p; a.addv = c; a.dx16 = d16.p; a.dx16v = c; a.dgamma = ddg.p; a.dbeta = ddb.p;
+  const int rc = launch_ln_bwd(a, H, OP_F16, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> out = dout.get(), dgo = ddg.get(), dbo = ddb.get();
+  std::vector<uint16_t> o16 = d16.get();
+  std::vector<double> dgr(dg0.begin(), dg0.end()), dbr(db0.begin(), db0.end());
+  double worst = rc ? 1e30 : 0, worst16 = worst;
+  for (int m = 0; m < rows && !rc; ++m) {
+    const float* xr = x.data() + off * H + voff(v, m);
+    double mu = 0, var = 0;
+    for (int i = 0; i < H; ++i) mu += xr[i];
+    mu /= H;
+    for (int i = 0; i < H; ++i) var += (xr[i] - mu) * (xr[i] - mu);
+    var /= H;
+    const double rstd = 1 / sqrt(var + 1e-12);
+    double sg = 0, sgx = 0;
+    for (int i = 0; i < H; ++i) { const double xh = (xr[i] - mu) * rstd, gg = (double)dy[(size_t)m * H + i] * g[i]; sg += gg; sgx += gg * xh; }
+    sg /= H; sgx /= H;
+    for (int i = 0; i < H; ++i) {
+      const double xh = (xr[i] - mu) * rstd, gg = (double)dy[(size_t)m * H + i] * g[i];
+      const double ref = rstd * (gg - sg - xh * sgx) + add[(size_t)m * H + i];
+      worst = std::max(worst, fabs(ref - out[off * H + voff(v, m) + i]) / (1 + fabs(ref)));
+      worst16 = std::max(worst16, fabs(ref - from_op(o16[(size_t)m * H + i], OP_F16)) / (1 + fabs(ref)));
+      dgr[i] += (double)dy[(size_t)m * H + i] * xh;
+      dbr[i] += dy[(size_t)m * H + i];
+    }
+  }
+  double worstp = rc ? 1e30 : 0;
+  for (int i = 0; i < H; ++i) worstp = std::max({worstp, fabs(dgr[i] - dgo[i]) / (1 + fabs(dgr[i])), fabs(dbr[i] - dbo[i]) / (1 + fabs(dbr[i]))});
+  report("ln_bwd dx (+ residual stream)", worst, 2e-5);
+  report("ln_bwd dx operand-dtype copy", worst16, 1e-3);
+  report("ln_bwd dgamma / dbeta (atomics)", worstp, 2e-5);
+}
+
+static void test_gelu_transpose_embed() {
+  const long long n = 4096;
+  std::vector<uint16_t> u(n), df(n);
+  for (auto& v : u) v = to_op(frand(2.f), OP_F16);
+  for (auto& v : df) v = to_op(frand(), OP_F16);
+  Dev<uint16_t> du(u), ddf(df), df_(n), db_(n);
+  int rc = launch_gelu(du.p, nullptr, df_.p, n, 0, OP_F16, 0) | launch_gelu(du.p, ddf.p, db_.p, n, 1, OP_F16, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> f = df_.get(), b = db_.get();
+  double w1 = rc ? 1e30 : 0, w2 = w1;
+  for (long long i = 0; i < n && !rc; ++i) {
+    const double x = from_op(u[i], OP_F16), d = from_op(df[i], OP_F16);
+    const double ge = 0.5 * x * (1 + erf(x / sqrt(2.0))), gp = 0.5 * (1 + erf(x / sqrt(2.0))) + x * exp(-0.5 * x * x) / sqrt(2 * M_PI);
+    w1 = std::max(w1, fabs(ge - from_op(f[i], OP_F16)) / (1 + fabs(ge)));
+    w2 = std::max(w2, fabs(d * gp - from_op(b[i], OP_F16)) / (1 + fabs(d * gp)));
+  }
+  report("gelu forward (elementwise)", w1, 1e-3);
+  report("gelu backward (elementwise)", w2, 1e-3);
+  const int R = 70, C = 45;
+  std::vector<uint16_t> m((size_t)R * C);
+  for (size_t i = 0; i < m.size(); ++i) m[i] = (uint16_t)i;
+  Dev<uint16_t> dm(m), dt((size_t)R * C);
+  rc = launch_transpose16(dm.p, dt.p, R, C, OP_F16, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> t = dt.get();
+  int bad = rc ? 1 : 0;
+  for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) bad += t[(size_t)c * R + r] != m[(size_t)r * C + c];
+  report("transpose16 (mismatches)", bad, 0);
+  // embeddings backward
+  const int items = 3, L = 4, Q = 32, H = 256, vocab = 10, S = Q + L;
+  std::vector<float> de((size_t)items * S * H);
+  for (auto& v : de) v = frand();
+  std::vector<long long> ids = {1, 9, 1, 0, 3, 3, 3, 2, 9, 8, 7, 1};
+  Dev<float> dde(de), dq((size_t)Q * H), dp((size_t)L * H), dw((size_t)vocab * H);
+  dq.fill(0); dp.fill(0); dw.fill(0);
+  Dev<long long> dids(ids);
+  rc = launch_embed_bwd(dde.p, dids.p, items, L, Q, H, vocab, dq.p, dp.p, dw.p, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> q = dq.get(), pp = dp.get(), w = dw.get();
+  std::vector<double> qr((size_t)Q * H, 0), pr((size_t)L * H, 0), wr((size_t)vocab * H, 0);
+  for (int n2 = 0; n2 < items; ++n2) for (int s2 = 0; s2 < S; ++s2) for (int c = 0; c < H; ++c) {
+    const double g = de[((size_t)n2 * S + s2) * H + c];
+    if (s2 < Q) qr[(size_t)s2 * H + c] += g; else { pr[(size_t)(s2 - Q) * H + c] += g; wr[(size_t)ids[n2 * L + s2 - Q] * H + c] += g; }
+  }
+  double we = rc ? 1e30 : 0;
+  for (size_t i = 0; i < qr.size(); ++i) we = std::max(we, fabs(qr[i] - q[i]));
+  for (size_t i = 0; i < pr.size(); ++i) we = std::max(we, fabs(pr[i] - pp[i]));
+  for (size_t i = 0; i < wr.size(); ++i) we = std::max(we, fabs(wr[i] - w[i]));
+  report("embed_bwd (query / position / word grads)", we, 1e-5);
+}
+
+// attention backward + the forward's LSE: self (packed QKV, mask) or cross (head-major)
+static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool self) {
+  const int op = OP_F16, H = heads * 64, ldqkv = 3 * H;
+  std::vector<uint16_t> Q, K, V, dO((size_t)items * q_rows * H);
+  std::vector<long long> mask;
+  if (self) {
+    Q.resize((size_t)items * q_rows * ldqkv);
+    for (auto& v : Q) v = to_op(frand(), op);
+    mask.assign((size_t)items * kv_len, 1);
+    for (int n = 0; n < items; ++n) for (int t = 32 + (n * 5) % (kv_len - 31); t < kv_len; ++t) mask[(size_t)n * kv_len + t] = 0;
+  } else {
+    Q.resize((size_t)items * q_rows * H); K.resize((size_t)items * heads * kv_len * 64); V.resize(K.size());
+    for (auto& v : Q) v = to_op(frand(), op);
+    for (auto& v : K) v = to_op(frand(), op);
+    for (auto& v : V) v = to_op(frand(), op);
+  }
+  for (auto& v : dO) v = to_op(frand(), op);
+  Dev<uint16_t> dQ_(Q), dK_(K), dV_(V), ddO(dO), dOut((size_t)items * q_rows * H);
+  Dev<long long> dM(mask);
+  Dev<float> dlse((size_t)items * heads * q_rows);
+  Dev<uint16_t> gQ(self ? Q.size() : Q.size()), gK(self ? 1 : K.size()), gV(self ? 1 : V.size());
+  gQ.fill(0);
+  AttnArgs f;
+  memset(&f, 0, sizeof(f));
+  AttnBwdArgs b;
+  memset(&b, 0, sizeof(b));
+  f.Q = dQ_.p; f.O = dOut.p; f.o_item_stride = (long long)q_rows * H; f.o_ld = H;
+  if (self) {
+    f.K = dQ_.p + H; f.V = dQ_.p + 2 * H;
+    f.q_item_stride = f.k_item_stride = f.v_item_stride = (long long)q_rows * ldqkv;
+    f.q_ld = f.k_ld = f.v_ld = ldqkv; f.k_head_stride = f.v_head_stride = 64;
+    f.mask = dM.p; f.mask_ld = kv_len;
+    b.dQ = gQ.p; b.dK = gQ.p + H; b.dV = gQ.p + 2 * H;
+    b.dq_item_stride = b.dk_item_stride = b.dv_item_stride = f.q_item_stride; b.dq_ld = b.dk_ld = b.dv_ld = ldqkv;
+    b.dk_head_stride = b.dv_head_stride = 64;
+  } else {
+    f.K = dK_.p; f.V = dV_.p; f.q_item_stride = (long long)q_rows * H; f.q_ld = H;
+    f.k_item_stride = f.v_item_stride = (long long)heads * kv_len * 64; f.k_head_stride = f.v_head_stride = (long long)kv_len * 64;
+    f.k_ld = f.v_ld = 64;
+    b.dQ = gQ.p; b.dK = gK.p; b.dV = gV.p; b.dq_item_stride = f.q_item_stride; b.dq_ld = H;
+    b.dk_item_stride = b.dv_item_stride = f.k_item_stride; b.dk_head_stride = b.dv_head_stride = f.k_head_stride; b.dk_ld = b.dv_ld = 64;
+  }
+  f.items = items; f.heads = heads; f.q_rows = q_rows; f.kv_len = kv_len; f.scale = 0.125f; f.nsplit = 1; f.lse = dlse.p;
+  int rc = launch_attention(f, op, 0);
+  b.Q = f.Q; b.K = f.K; b.V = f.V; b.O = dOut.p; b.dO = ddO.p;
+  b.q_item_stride = f.q_item_stride; b.o_item_stride = f.o_item_stride; b.q_ld = f.q_ld; b.o_ld = f.o_ld;
+  b.k_item_stride = f.k_item_stride; b.k_head_stride = f.k_head_stride; b.v_item_stride = f.v_item_stride; b.v_head_stride = f.v_head_stride;
+  b.k_ld = f.k_ld; b.v_ld = f.v_ld; b.mask = f.mask; b.mask_ld = f.mask_ld; b.lse = dlse.p;
+  b.items = items; b.heads = heads; b.q_rows = q_rows; b.kv_len = kv_len; b.scale = 0.125f;
+  rc |= launch_attn_bwd(b, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> rQ = gQ.get(), rK = gK.get(), rV = gV.get();
+  std::vector<float> lse = dlse.get();
+  double wl = rc ? 1e30 : 0, wq = wl, wk = wl, wv = wl;
+  std::vector<double> p(kv_len), dp(kv_len);
+  for (int n = 0; n < items && !rc; ++n)
+    for (int h = 0; h < heads; ++h) {
+      std::vector<double> dK((size_t)kv_len * 64, 0), dV((size_t)kv_len * 64, 0);
+      auto kp = [&](int t) { return self ? Q.data() + ((size_t)n * q_rows + t) * ldqkv + H + h * 64 : K.data() + (((size_t)n * heads + h) * kv_len + t) * 64; };
+      auto vp = [&](int t) { return self ? Q.data() + ((size_t)n * q_rows + t) * ldqkv + 2 * H + h * 64 : V.data() + (((size_t)n * heads + h) * kv_len + t) * 64; };
+      for (int q = 0; q < q_rows; ++q) {
+        const uint16_t* qp = self ? Q.data() + ((size_t)n * q_rows + q) * ldqkv + h * 64 : Q.data() + ((size_t)n * q_rows + q) * H + h * 64;
+        const uint16_t* dop = dO.data() + ((size_t)n * q_rows + q) * H + h * 64;
+        double mx = -1e300;
+        for (int t = 0; t < kv_len; ++t) {
+          double acc = 0;
+          for (int d = 0; d < 64; ++d) acc += (double)from_op(qp[d], op) * from_op(kp(t)[d], op);
+          acc *= 0.125;
+          if (self) acc += (1.0 - (double)mask[(size_t)n * kv_len + t]) * -10000.0;
+          p[t] = acc; mx = std::max(mx, acc);
+        }
+        double den = 0;
+        for (int t = 0; t < kv_len; ++t) { p[t] = exp(p[t] - mx); den += p[t]; }
+        const double lref = (mx + log(den)) / log(2.0);
+        wl = std::max(wl, fabs(lref - lse[((size_t)n * heads + h) * q_rows + q]) / (1 + fabs(lref)));
+        double delta = 0;
+        for (int t = 0; t < kv_len; ++t) {
+          p[t] /= den;
+          double acc = 0;
+          for (int d = 0; d < 64; ++d) acc += (double)from_op(dop[d], op) * from_op(vp(t)[d], op);
+          dp[t] = acc; delta += p[t] * acc;
+        }
+        for (int d = 0; d < 64; ++d) {
+          double dq = 0;
+          for (int t = 0; t < kv_len; ++t) dq += p[t] * (dp[t] - delta) * 0.125 * from_op(kp(t)[d], op);
+          const size_t qi = self ? ((size_t)n * q_rows + q) * ldqkv + h * 64 + d : ((size_t)n * q_rows + q) * H + h * 64 + d;
+          wq = std::max(wq, fabs(dq - from_op(rQ[qi], op)));
+        }
+        for (int t = 0; t < kv_len; ++t) {
+          const double ds = p[t] * (dp[t] - delta) * 0.125;
+          for (int d = 0; d < 64; ++d) { dK[(size_t)t * 64 + d] += ds * from_op(qp[d], op); dV[(size_t)t * 64 + d] += p[t] * from_op(dop[d], op); }
+        }
+      }
+      for (int t = 0; t < kv_len; ++t) for (int d = 0; d < 64; ++d) {
+        const size_t ki = self ? ((size_t)n * q_rows + t) * ldqkv + H + h * 64 + d : (((size_t)n * heads + h) * kv_len + t) * 64 + d;
+        const size_t vi = self ? ki + H : ki;
+        wk = std::max(wk, fabs(dK[(size_t)t * 64 + d] - from_op(self ? rQ[ki] : rK[ki], op)));
+        wv = std::max(wv, fabs(dV[(size_t)t * 64 + d] - from_op(self ? rQ[vi] : rV[vi], op)));
+      }
+    }
+  char name[96];
+  snprintf(name, sizeof(name), "attn %s items%d heads%d q%d kv%d", self ? "self" : "cross", items, heads, q_rows, kv_len);
+  report(std::string(name) + " forward LSE", wl, 2e-3);
+  report(std::string(name) + " backward dQ", wq, 6e-3);
+  report(std::string(name) + " backward dK", wk, 6e-3);
+  report(std::string(name) + " backward dV", wv, 6e-3);
+}
+
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   int dev = 0;
@@ -528,6 +740,11 @@ int main(int argc, char** argv) {
   test_gemm_tn(OP_F16, 1040, 128, 192, false, true);
   test_gemm_tn(OP_BF16, 333, 192, 128, false, false);
   test_gemm_tn(OP_F16, 300, 128, 64, true, true);
+  test_ln_bwd();
+  test_gelu_transpose_embed();
+  test_attn_bwd(3, 2, 45, 45, true);
+  test_attn_bwd(2, 2, 160, 160, true);
+  test_attn_bwd(3, 2, 32, 257, false);
   test_ln_rows(OP_F16);
   test_ln_rows(OP_BF16);
   test_modality_ln(0, 1408);
