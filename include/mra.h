@@ -147,6 +147,32 @@ int mra_fuse_logits(const float* const* logits, const float* weights, int32_t nm
 int mra_span_from_logits(const float* logits, int32_t videos, int32_t clips, float alpha, int32_t* spans,
                          void* stream);
 
+/* ---- training: forward with an activation tape + backward (BASELINE config 5) --------------------
+ * Beyond the reference: its Q-Formers are frozen (models/xinstructblip.py:196-204) and utils/trainer.py
+ * only updates LoRA adapters of the LLM; the north star asks for a Q-Former fwd+bwd step.  Checked
+ * against torch.autograd over the CPU oracle.
+ *   mra_qformer_enable_training   builds the transposed weight copies the data-gradient GEMMs read
+ *                                 (allocates once; call again after every weight upload)
+ *   mra_qformer_forward_train     as mra_qformer_forward (loaded query tokens, optional out_cls) but
+ *                                 every layer keeps its activations in `workspace`, which must stay
+ *                                 untouched until the matching mra_qformer_backward
+ *   mra_qformer_backward          d_out_query [items, n_query, hidden] and/or d_out_cls [items, hidden]
+ *                                 (f32, NULL = zero) -> ADDS parameter gradients into `grads`, a flat f32
+ *                                 buffer of mra_qformer_grad_bytes() in which parameter `name` (same names
+ *                                 as mra_qformer_load) owns numel floats at mra_qformer_grad_offset().
+ *                                 Gradients flow to every Q-Former parameter incl. query_tokens and the
+ *                                 embeddings; not to enc / ln.* / llm_proj.* (encoder side frozen). */
+size_t mra_qformer_grad_bytes(mra_qformer* h);
+int mra_qformer_grad_offset(mra_qformer* h, const char* name, size_t* offset_bytes, int64_t* numel);
+int mra_qformer_enable_training(mra_qformer* h, void* stream);
+size_t mra_qformer_train_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv);
+int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
+                              int32_t items, int32_t L, int32_t kv, float* out_query, float* out_cls, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
+                         int32_t items, int32_t L, int32_t kv, const float* d_out_query, const float* d_out_cls,
+                         float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- introspection for the bench ------------------------------------------------------------------
  * Algorithmic flop count of one mra_qformer_forward (2 flops per MAC; formula in DESIGN.md). */
 double mra_qformer_flops(mra_qformer* h, int32_t items, int32_t L, int32_t kv, int32_t with_last_text);

@@ -54,6 +54,14 @@ PROTOTYPES = {
     "mra_fuse_logits": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     "mra_span_from_logits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "mra_qformer_grad_bytes": (C.c_size_t, [C.c_void_p]),
+    "mra_qformer_grad_offset": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "mra_qformer_enable_training": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mra_qformer_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "mra_qformer_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mra_qformer_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mra_qformer_flops": (C.c_double, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
 }
 

@@ -149,7 +149,7 @@ int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, 
 int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query,
                     long long query_item_stride, const float* word,
                     const float* pos, const float* gain, const float* bias, float eps, float* h32, void* h16,
-                    int op_dtype, hipStream_t stream);
+                    float* pre32 /* optional: rows before the LayerNorm (training) */, int op_dtype, hipStream_t stream);
 // dst(op dtype)[rows][cols] at row offset <- src (0 = f32, 1 = f16, 2 = bf16)
 int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype /*0 f32,1 f16,2 bf16*/, long long n,
                    hipStream_t stream);

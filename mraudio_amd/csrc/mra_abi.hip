@@ -11,95 +11,32 @@
 //     through row views (no slicing copies); the two feed-forwards run as one grouped launch;
 //   * residual stream, LayerNorm statistics and softmax are fp32; only MFMA operands are f16/bf16.
 // No allocation and no synchronisation after create/load; everything is enqueued on `stream`.
-#include <hip/hip_runtime.h>
-
 #include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
 
-#include "../../include/mra.h"
-#include "kernels.h"
+#include "mra_handle.h"
 
 using namespace mra;
+using namespace mra_host;
 
-namespace {
-
+namespace mra_host {
 thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
 }
 
-#define HIP_TRY(expr)                                                                            \
-  do {                                                                                           \
-    hipError_t e_ = (expr);                                                                      \
-    if (e_ != hipSuccess) return fail(MRA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-
-size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
-
-struct Param {
-  void* ptr = nullptr;   // destination inside the arena
-  int dtype = MRA_F32;   // stored dtype
-  long long numel = 0;   // elements expected from the source tensor
-  bool loaded = false;
-};
-
-struct LayerW {
-  void *wqkv, *wo, *wcq, *wco, *wiq, *woq, *wit, *wot;
-  float *bqkv, *bo, *bcq, *bco, *biq, *boq, *bit, *bot;
-  float *ln1g, *ln1b, *lncg, *lncb, *lnqg, *lnqb, *lntg, *lntb;
-  int cross_index;  // -1 when the layer has no cross-attention
-};
-
-}  // namespace
-
-struct mra_qformer {
-  mra_cfg cfg;
-  int device = 0;
-  int ncross = 0;
-  char* arena = nullptr;
-  size_t arena_bytes = 0;
-  std::map<std::string, Param> params;
-  std::vector<LayerW> layers;
-  // embeddings / extras
-  float *word = nullptr, *pos = nullptr, *embg = nullptr, *embb = nullptr, *query = nullptr;
-  float *encg = nullptr, *encb = nullptr;
-  void* wkv = nullptr;  // [ncross*2*H, E]
-  float* bkv = nullptr;
-  void* wllm = nullptr;
-  float* bllm = nullptr;
-  hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
-  int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
-};
-
 namespace {
-
-struct Carver {
-  char* base;
-  size_t off = 0;
-  explicit Carver(char* b) : base(b) {}
-  template <typename T>
-  T* take(size_t count, size_t elem = sizeof(T)) {
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += align_up(count * elem);
-    return p;
-  }
-};
 
 // Lays the parameter arena out; with base == nullptr only measures.
 size_t layout_params(mra_qformer* h, char* base) {
   const mra_cfg& c = h->cfg;
   const size_t H = c.hidden, I = c.inter, E = c.enc_width;
   Carver cv(base);
+  size_t goff = 0;
   auto reg = [&](const std::string& name, void* p, int dtype, long long numel) {
     Param pr;
     pr.ptr = p;
     pr.dtype = dtype;
     pr.numel = numel;
+    pr.goff = goff;  // gradients: one f32 block per parameter, registration order
+    goff += align_up((size_t)numel * 4);
     h->params[name] = pr;
   };
   const int opd = c.op_dtype;
@@ -197,6 +134,7 @@ size_t layout_params(mra_qformer* h, char* base) {
     reg(p + "output_query.LayerNorm.weight", L.lnqg, MRA_F32, H);
     reg(p + "output_query.LayerNorm.bias", L.lnqb, MRA_F32, H);
   }
+  h->grad_bytes = goff;
   return cv.off;
 }
 
@@ -231,16 +169,9 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   return w;
 }
 
-RowView plain(int rows, int ld) { return RowView{0, rows > 0 ? rows : 1, ld}; }
-RowView items_view(long long item_stride, int rpi, int ld) { return RowView{item_stride, rpi, ld}; }
+}  // namespace
 
-hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-int chk(int rc, const char* what) {
-  if (rc == 0) return 0;
-  return fail(rc == -1 ? MRA_EINVAL : MRA_EHIP, std::string(what) + " failed (rc " + std::to_string(rc) + ")");
-}
-
+namespace mra_host {
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream) {
   const mra_cfg& c = h->cfg;
@@ -260,7 +191,7 @@ int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_ca
   return launch_gemm(&p, 1, EPI_KV, h->op(), stream);
 }
 
-}  // namespace
+}  // namespace mra_host
 
 extern "C" {
 
@@ -311,6 +242,7 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
 void mra_qformer_destroy(mra_qformer* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
+  if (h->arena_t) (void)hipFree(h->arena_t);
   delete h;
 }
 
@@ -330,6 +262,7 @@ int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t 
   const int rc = launch_convert(src, dtype, it->second.ptr, it->second.dtype, numel, as_stream(stream));
   if (rc) return chk(rc, "launch_convert");
   it->second.loaded = true;
+  h->transposes_stale = true;
   return MRA_OK;
 }
 
@@ -426,7 +359,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
   const float* qsrc = query_embeds ? query_embeds : h->query;
   const long long qstride = query_embeds && query_items == items && items > 1 ? (long long)Q * H : 0;
   int rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, c.vocab, qsrc, qstride, h->word, h->pos, h->embg,
-                           h->embb, c.ln_eps, w.hA32, w.hA16, op, stream);
+                           h->embb, c.ln_eps, w.hA32, w.hA16, nullptr, op, stream);
   if (rc) return chk(rc, "embed_ln");
 
   // K/V of every cross layer in one GEMM, scattered head-major

@@ -1,0 +1,99 @@
+// Private to the library: the handle behind include/mra.h, its parameter registry and small host helpers
+// shared by the inference path (mra_abi.hip) and the training path (mra_train.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mra.h"
+#include "kernels.h"
+
+namespace mra_host {
+
+using namespace mra;
+
+extern thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(MRA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Param {
+  void* ptr = nullptr;   // destination inside the arena
+  int dtype = MRA_F32;   // stored dtype
+  long long numel = 0;   // elements expected from the source tensor
+  bool loaded = false;
+  size_t goff = 0;       // byte offset of this parameter's f32 gradient in the flat gradient buffer
+  int rows = 0, cols = 0;  // matrix shape ([out, in]) for weights, 0 otherwise
+};
+
+struct LayerW {
+  void *wqkv, *wo, *wcq, *wco, *wiq, *woq, *wit, *wot;
+  float *bqkv, *bo, *bcq, *bco, *biq, *boq, *bit, *bot;
+  float *ln1g, *ln1b, *lncg, *lncb, *lnqg, *lnqb, *lntg, *lntb;
+  int cross_index;  // -1 when the layer has no cross-attention
+  // transposed copies for the data-gradient GEMMs (training only; nullptr until mra_qformer_enable_training)
+  void *wqkvT, *woT, *wcqT, *wcoT, *wiqT, *woqT, *witT, *wotT;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count, size_t elem = sizeof(T)) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(count * elem);
+    return p;
+  }
+};
+
+inline RowView plain(int rows, int ld) { return RowView{0, rows > 0 ? rows : 1, ld}; }
+inline RowView items_view(long long item_stride, int rpi, int ld) { return RowView{item_stride, rpi, ld}; }
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int chk(int rc, const char* what) {
+  if (rc == 0) return 0;
+  return fail(rc == -1 ? MRA_EINVAL : MRA_EHIP, std::string(what) + " failed (rc " + std::to_string(rc) + ")");
+}
+
+}  // namespace mra_host
+
+struct mra_qformer {
+  mra_cfg cfg;
+  int device = 0;
+  int ncross = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::map<std::string, mra_host::Param> params;
+  std::vector<mra_host::LayerW> layers;
+  // embeddings / extras
+  float *word = nullptr, *pos = nullptr, *embg = nullptr, *embb = nullptr, *query = nullptr;
+  float *encg = nullptr, *encb = nullptr;
+  void* wkv = nullptr;  // [ncross*2*H, E]
+  float* bkv = nullptr;
+  void* wllm = nullptr;
+  float* bllm = nullptr;
+  hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
+  // training
+  char* arena_t = nullptr;      // transposed weight copies
+  bool transposes_stale = true;
+  size_t grad_bytes = 0;
+  int op() const { return cfg.op_dtype == MRA_BF16 ? mra::OP_BF16 : mra::OP_F16; }
+};
+
+namespace mra_host {
+// K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
+int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);
+}  // namespace mra_host

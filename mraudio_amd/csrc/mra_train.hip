@@ -1,0 +1,424 @@
+// Training path of the Q-Former: forward that keeps an activation tape, and the full backward.
+//
+// BASELINE config 5 ("finetune.py step: Q-Former fwd+bwd with fused LN/GELU grads").  The reference
+// itself never trains its Q-Formers (frozen, models/xinstructblip.py:196-204; the trainer only updates
+// LoRA adapters of the LLM, utils/trainer.py:124-140), so the definition of correct is torch.autograd
+// over the CPU oracle.  Layer structure as in the inference path (mra_abi.hip / HF:591-709).
+//
+// Gradients: one flat f32 buffer, one block per parameter (mra_qformer_grad_offset); every call ADDS
+// into it (the caller zeroes it when it wants fresh gradients), which is what gradient accumulation
+// (utils/trainer.py:31,137) needs.  Data-gradient GEMMs reuse the forward GEMM kernels on transposed
+// weight copies (built by mra_qformer_enable_training, refreshed after every weight upload); weight
+// gradients use gemm_tn.hip; LayerNorm / GELU / attention / embedding gradients backward.hip.
+#include "mra_handle.h"
+
+using namespace mra;
+using namespace mra_host;
+
+namespace {
+
+struct LayerBuf {
+  float* hin32; char* hin16;
+  char* qkv16; float* lse_s; char* ctx16;
+  float* pre1; float* h1_32; char* h1_16;
+  char* qc16; float* lse_c; char* cctx16; float* pre2; float* hc32; char* hc16;
+  char* u16; char* f16;
+  float* pre3;
+};
+
+struct TrainBufs {
+  std::vector<LayerBuf> layer;
+  float* emb_pre; float* out32; char* out16;
+  char* kv16; float* part; int nsplit;
+  // backward scratch
+  float *dhA, *dhB, *dpre32, *dhc32, *dpre2_32;
+  char *dpre16, *dff16, *dctx16, *dqkv16, *dpre2_16, *dcctx16, *dqc16, *dkv16;
+  size_t bytes;
+};
+
+TrainBufs layout_train(const mra_qformer* h, char* base, int N, int L, int Kv) {
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, I = c.inter, S = c.n_query + L, Q = c.n_query, heads = c.heads;
+  Carver cv(base);
+  TrainBufs t;
+  t.layer.resize(c.layers);
+  for (int i = 0; i < c.layers; ++i) {
+    LayerBuf& b = t.layer[i];
+    b.hin32 = cv.take<float>(N * S * H);
+    b.hin16 = cv.take<char>(N * S * H, 2);
+    b.qkv16 = cv.take<char>(N * S * 3 * H, 2);
+    b.lse_s = cv.take<float>(N * heads * S);
+    b.ctx16 = cv.take<char>(N * S * H, 2);
+    b.pre1 = cv.take<float>(N * S * H);
+    b.h1_32 = cv.take<float>(N * S * H);
+    b.h1_16 = cv.take<char>(N * S * H, 2);
+    if (h->layers[i].cross_index >= 0) {
+      b.qc16 = cv.take<char>(N * Q * H, 2);
+      b.lse_c = cv.take<float>(N * heads * Q);
+      b.cctx16 = cv.take<char>(N * Q * H, 2);
+      b.pre2 = cv.take<float>(N * Q * H);
+      b.hc32 = cv.take<float>(N * Q * H);
+      b.hc16 = cv.take<char>(N * Q * H, 2);
+    } else {
+      b.qc16 = b.cctx16 = b.hc16 = nullptr;
+      b.lse_c = b.pre2 = b.hc32 = nullptr;
+    }
+    b.u16 = cv.take<char>(N * S * I, 2);
+    b.f16 = cv.take<char>(N * S * I, 2);
+    b.pre3 = cv.take<float>(N * S * H);
+  }
+  t.emb_pre = cv.take<float>(N * S * H);
+  t.out32 = cv.take<float>(N * S * H);
+  t.out16 = cv.take<char>(N * S * H, 2);
+  t.kv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
+  t.nsplit = attn_pick_split(N, c.heads, (int)Q, Kv);
+  t.part = cv.take<float>(attn_partial_bytes(N, c.heads, (int)Q, t.nsplit) / 4 + 64);
+  t.dhA = cv.take<float>(N * S * H);
+  t.dhB = cv.take<float>(N * S * H);
+  t.dpre32 = cv.take<float>(N * S * H);
+  t.dhc32 = cv.take<float>(N * Q * H);
+  t.dpre2_32 = cv.take<float>(N * Q * H);
+  t.dpre16 = cv.take<char>(N * S * H, 2);
+  t.dff16 = cv.take<char>(N * S * I, 2);
+  t.dctx16 = cv.take<char>(N * S * H, 2);
+  t.dqkv16 = cv.take<char>(N * S * 3 * H, 2);
+  t.dpre2_16 = cv.take<char>(N * Q * H, 2);
+  t.dcctx16 = cv.take<char>(N * Q * H, 2);
+  t.dqc16 = cv.take<char>(N * Q * H, 2);
+  t.dkv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
+  t.bytes = cv.off;
+  return t;
+}
+
+size_t layout_transposes(mra_qformer* h, char* base) {
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, I = c.inter;
+  Carver cv(base);
+  for (int i = 0; i < c.layers; ++i) {
+    LayerW& L = h->layers[i];
+    L.wqkvT = cv.take<char>(3 * H * H, 2);
+    L.woT = cv.take<char>(H * H, 2);
+    if (L.cross_index >= 0) {
+      L.wcqT = cv.take<char>(H * H, 2);
+      L.wcoT = cv.take<char>(H * H, 2);
+    }
+    L.wiqT = cv.take<char>(I * H, 2);
+    L.woqT = cv.take<char>(I * H, 2);
+    L.witT = cv.take<char>(I * H, 2);
+    L.wotT = cv.take<char>(I * H, 2);
+  }
+  return cv.off;
+}
+
+int refresh_transposes(mra_qformer* h, hipStream_t stream) {
+  const mra_cfg& c = h->cfg;
+  const int H = c.hidden, I = c.inter, op = h->op();
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& L = h->layers[i];
+    int rc = launch_transpose16(L.wqkv, L.wqkvT, 3 * H, H, op, stream);
+    rc |= launch_transpose16(L.wo, L.woT, H, H, op, stream);
+    if (L.cross_index >= 0) {
+      rc |= launch_transpose16(L.wcq, L.wcqT, H, H, op, stream);
+      rc |= launch_transpose16(L.wco, L.wcoT, H, H, op, stream);
+    }
+    rc |= launch_transpose16(L.wiq, L.wiqT, I, H, op, stream);
+    rc |= launch_transpose16(L.woq, L.woqT, H, I, op, stream);
+    rc |= launch_transpose16(L.wit, L.witT, I, H, op, stream);
+    rc |= launch_transpose16(L.wot, L.wotT, H, I, op, stream);
+    if (rc) return rc;
+  }
+  h->transposes_stale = false;
+  return 0;
+}
+
+struct Ctx {
+  mra_qformer* h;
+  hipStream_t stream;
+  int op;
+  // forward-kernel GEMM:  C = A W^T (+bias) (+R)
+  int gemm(const void* A, RowView av, const void* W, const float* bias, void* C, RowView cv, const float* R, RowView rv, int M, int N,
+           int K, int epi) const {
+    if (M <= 0) return 0;
+    GemmProb p{};
+    p.A = A; p.a = av; p.W = W; p.bias = bias; p.C = C; p.c = cv; p.R = R; p.r = rv;
+    p.M = M; p.N = N; p.K = K;
+    return launch_gemm(&p, 1, epi, op, stream);
+  }
+  // dW += dY^T X, db += colsum(dY); dY given as [M, ldy] row view starting at column block `cb0`
+  int wgrad(const void* dY, RowView yv, long long y_block_stride, const void* X, RowView xv, int M, int N, int K, float* dW, float* db) const {
+    if (M <= 0) return 0;
+    GemmTnArgs a{};
+    a.dY = dY; a.X = X; a.dW = dW; a.yv = yv; a.xv = xv; a.y_block_stride = y_block_stride; a.x_block_stride = 64;
+    a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1;
+    int rc = launch_gemm_tn(a, op, stream);
+    if (!rc && db) rc = launch_colsum(dY, y_block_stride, yv, M, N, db, 1, op, stream);
+    return rc;
+  }
+};
+
+float* gptr(mra_qformer* h, float* grads, const std::string& name) {
+  auto it = h->params.find(name);
+  return it == h->params.end() ? nullptr : grads + it->second.goff / 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mra_qformer_grad_bytes(mra_qformer* h) { return h ? h->grad_bytes : 0; }
+
+int mra_qformer_grad_offset(mra_qformer* h, const char* name, size_t* offset_bytes, int64_t* numel) {
+  if (!h || !name) return fail(MRA_EINVAL, "null argument");
+  auto it = h->params.find(name);
+  if (it == h->params.end()) return fail(MRA_ENAME, std::string("unknown parameter name: ") + name);
+  if (offset_bytes) *offset_bytes = it->second.goff;
+  if (numel) *numel = it->second.numel;
+  return MRA_OK;
+}
+
+int mra_qformer_enable_training(mra_qformer* h, void* stream) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (!h->arena_t) {
+    const size_t bytes = layout_transposes(h, nullptr);
+    hipError_t e = hipMalloc((void**)&h->arena_t, bytes);
+    if (e != hipSuccess) return fail(MRA_ENOMEM, std::string("hipMalloc of transposed weights: ") + hipGetErrorString(e));
+    layout_transposes(h, h->arena_t);
+    h->transposes_stale = true;
+  }
+  if (h->transposes_stale) return chk(refresh_transposes(h, as_stream(stream)), "weight transposes");
+  return MRA_OK;
+}
+
+size_t mra_qformer_train_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv) {
+  if (!h || items <= 0 || L < 0 || kv <= 0) return 0;
+  return layout_train(h, nullptr, items, L, kv).bytes;
+}
+
+int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
+                              int32_t items, int32_t L, int32_t kv, float* out_query, float* out_cls, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (items <= 0 || L < 0 || kv <= 0) return fail(MRA_EINVAL, "bad sizes");
+  const mra_cfg& c = h->cfg;
+  if (L > c.max_pos || !enc || (L > 0 && !input_ids) || (out_cls && L < 1)) return fail(MRA_EINVAL, "bad arguments");
+  if (!workspace || workspace_bytes < mra_qformer_train_workspace_bytes(h, items, L, kv) || reinterpret_cast<uintptr_t>(workspace) % 256)
+    return fail(MRA_ENOMEM, "training workspace too small or misaligned");
+  hipStream_t stream = as_stream(stream_);
+  const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
+  const Ctx X{h, stream, h->op()};
+  const int op = X.op;
+  TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
+  const long long SH = (long long)S * H;
+  const RowView all_rows = plain(N * S, H), q_view = items_view(SH, Q, H), t_view = items_view(SH, L > 0 ? L : 1, H);
+  const RowView qc_rows = plain(N * Q, H);
+  const size_t t16 = (size_t)Q * H * 2, t32 = (size_t)Q * H;
+  int rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, c.vocab, h->query, 0, h->word, h->pos, h->embg, h->embb, c.ln_eps,
+                           t.layer[0].hin32, t.layer[0].hin16, t.emb_pre, op, stream);
+  if (rc) return chk(rc, "embed_ln");
+  if (h->ncross > 0 && (rc = kv_project(h, enc, N, kv, t.kv16, stream))) return chk(rc, "kv projection");
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& W = h->layers[i];
+    LayerBuf& b = t.layer[i];
+    float* nxt32 = i + 1 < c.layers ? t.layer[i + 1].hin32 : t.out32;
+    char* nxt16 = i + 1 < c.layers ? t.layer[i + 1].hin16 : t.out16;
+    if ((rc = X.gemm(b.hin16, all_rows, W.wqkv, W.bqkv, b.qkv16, plain(N * S, 3 * H), nullptr, all_rows, N * S, 3 * H, H, EPI_OP)))
+      return chk(rc, "qkv gemm");
+    {
+      AttnArgs a{};
+      a.Q = b.qkv16; a.K = b.qkv16 + (size_t)H * 2; a.V = b.qkv16 + (size_t)2 * H * 2; a.O = b.ctx16;
+      a.q_item_stride = a.k_item_stride = a.v_item_stride = (long long)S * 3 * H; a.q_ld = a.k_ld = a.v_ld = 3 * H;
+      a.k_head_stride = a.v_head_stride = 64; a.o_item_stride = SH; a.o_ld = H;
+      a.mask = (const long long*)attention_mask; a.mask_ld = S;
+      a.items = N; a.heads = c.heads; a.q_rows = S; a.kv_len = S; a.scale = 0.125f; a.nsplit = 1; a.lse = b.lse_s;
+      if ((rc = launch_attention(a, op, stream))) return chk(rc, "self attention");
+    }
+    if ((rc = X.gemm(b.ctx16, all_rows, W.wo, W.bo, b.pre1, all_rows, b.hin32, all_rows, N * S, H, H, EPI_RES_F32))) return chk(rc, "attn out gemm");
+    if ((rc = launch_ln_rows(b.pre1, all_rows, N * S, H, W.ln1g, W.ln1b, c.ln_eps, b.h1_32, all_rows, b.h1_16, all_rows, op, stream)))
+      return chk(rc, "attn ln");
+    const void* fq16 = b.h1_16; const float* fq32 = b.h1_32; RowView fqv = q_view;
+    if (W.cross_index >= 0) {
+      if ((rc = X.gemm(b.h1_16, q_view, W.wcq, W.bcq, b.qc16, qc_rows, nullptr, qc_rows, N * Q, H, H, EPI_OP))) return chk(rc, "cross q gemm");
+      AttnArgs a{};
+      const size_t per_sel = (size_t)N * c.heads * kv * 64;
+      a.Q = b.qc16; a.K = t.kv16 + (size_t)(W.cross_index * 2) * per_sel * 2; a.V = t.kv16 + (size_t)(W.cross_index * 2 + 1) * per_sel * 2;
+      a.O = b.cctx16; a.q_item_stride = a.o_item_stride = (long long)Q * H; a.q_ld = a.o_ld = H;
+      a.k_item_stride = a.v_item_stride = (long long)c.heads * kv * 64; a.k_head_stride = a.v_head_stride = (long long)kv * 64; a.k_ld = a.v_ld = 64;
+      a.items = N; a.heads = c.heads; a.q_rows = Q; a.kv_len = kv; a.scale = 0.125f; a.nsplit = t.nsplit; a.part = t.part; a.lse = b.lse_c;
+      if ((rc = launch_attention(a, op, stream))) return chk(rc, "cross attention");
+      if ((rc = X.gemm(b.cctx16, qc_rows, W.wco, W.bco, b.pre2, qc_rows, b.h1_32, q_view, N * Q, H, H, EPI_RES_F32))) return chk(rc, "cross out gemm");
+      if ((rc = launch_ln_rows(b.pre2, qc_rows, N * Q, H, W.lncg, W.lncb, c.ln_eps, b.hc32, qc_rows, b.hc16, qc_rows, op, stream))) return chk(rc, "cross ln");
+      fq16 = b.hc16; fq32 = b.hc32; fqv = qc_rows;
+    }
+    // feed-forwards: rows [0, N*Q) of u16 / f16 are the query rows, [N*Q, N*S) the text rows
+    char* u_t = b.u16 + (size_t)N * Q * I * 2;
+    char* f_t = b.f16 + (size_t)N * Q * I * 2;
+    if ((rc = X.gemm(fq16, fqv, W.wiq, W.biq, b.u16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_OP))) return chk(rc, "ffn-q up");
+    if ((rc = X.gemm(b.h1_16 + t16, t_view, W.wit, W.bit, u_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_OP))) return chk(rc, "ffn-t up");
+    if ((rc = launch_gelu(b.u16, nullptr, b.f16, (long long)N * S * I, 0, op, stream))) return chk(rc, "gelu");
+    if ((rc = X.gemm(b.f16, plain(N * Q, I), W.woq, W.boq, b.pre3, q_view, fq32, fqv, N * Q, H, I, EPI_RES_F32))) return chk(rc, "ffn-q down");
+    if ((rc = X.gemm(f_t, plain(N * L, I), W.wot, W.bot, b.pre3 + t32, t_view, b.h1_32 + t32, t_view, N * L, H, I, EPI_RES_F32))) return chk(rc, "ffn-t down");
+    if ((rc = launch_ln_rows(b.pre3, q_view, N * Q, H, W.lnqg, W.lnqb, c.ln_eps, nxt32, q_view, nxt16, q_view, op, stream))) return chk(rc, "ffn-q ln");
+    if (L > 0 && (rc = launch_ln_rows(b.pre3 + t32, t_view, N * L, H, W.lntg, W.lntb, c.ln_eps, nxt32 + t32, t_view, nxt16 + t16, t_view, op, stream)))
+      return chk(rc, "ffn-t ln");
+  }
+  if (out_query && (rc = launch_copy_rows_f32(t.out32, q_view, out_query, qc_rows, N * Q, H, stream))) return chk(rc, "copy out_query");
+  if (out_cls && (rc = launch_copy_rows_f32(t.out32 + t32, items_view(SH, 1, H), out_cls, plain(N, H), N, H, stream))) return chk(rc, "copy out_cls");
+  return MRA_OK;
+}
+
+int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc, int32_t items,
+                         int32_t L, int32_t kv, const float* d_out_query, const float* d_out_cls, float* grads, void* workspace,
+                         size_t workspace_bytes, void* stream_) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (items <= 0 || L < 0 || kv <= 0 || !grads || !enc) return fail(MRA_EINVAL, "bad arguments");
+  if (!d_out_query && !d_out_cls) return fail(MRA_EINVAL, "no upstream gradient");
+  if (!h->arena_t || h->transposes_stale) return fail(MRA_ESTATE, "call mra_qformer_enable_training after the last weight upload");
+  if (!workspace || workspace_bytes < mra_qformer_train_workspace_bytes(h, items, L, kv)) return fail(MRA_ENOMEM, "training workspace too small");
+  const mra_cfg& c = h->cfg;
+  hipStream_t stream = as_stream(stream_);
+  const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
+  const Ctx X{h, stream, h->op()};
+  const int op = X.op;
+  TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
+  const long long SH = (long long)S * H;
+  const RowView all_rows = plain(N * S, H), q_view = items_view(SH, Q, H), t_view = items_view(SH, L > 0 ? L : 1, H);
+  const RowView qc_rows = plain(N * Q, H);
+  const size_t t16 = (size_t)Q * H * 2, t32 = (size_t)Q * H;
+  int rc;
+  // upstream gradient of last_hidden_state: zeros, query rows <- d_out_query, [CLS] row <- d_out_cls
+  float* dh = t.dhA;     // gradient w.r.t. the current layer's output
+  float* dh1 = t.dhB;    // gradient w.r.t. the post-self-attention state h1
+  HIP_TRY(hipMemsetAsync(dh, 0, (size_t)N * S * H * 4, stream));
+  if (d_out_query && (rc = launch_copy_rows_f32(d_out_query, qc_rows, dh, q_view, N * Q, H, stream))) return chk(rc, "seed dq");
+  if (d_out_cls && (rc = launch_copy_rows_f32(d_out_cls, plain(N, H), dh + t32, items_view(SH, 1, H), N, H, stream))) return chk(rc, "seed dcls");
+  if (h->ncross > 0) HIP_TRY(hipMemsetAsync(t.dkv16, 0, (size_t)h->ncross * 2 * N * kv * H * 2, stream));
+  auto G = [&](const std::string& n) { return gptr(h, grads, n); };
+
+  for (int i = c.layers - 1; i >= 0; --i) {
+    const LayerW& W = h->layers[i];
+    const LayerBuf& b = t.layer[i];
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+    const void* fq16 = W.cross_index >= 0 ? (const void*)b.hc16 : (const void*)b.h1_16;
+    const RowView fqv = W.cross_index >= 0 ? qc_rows : q_view;
+    const char* u_t = b.u16 + (size_t)N * Q * I * 2;
+    const char* f_t = b.f16 + (size_t)N * Q * I * 2;
+    char* dff_t = t.dff16 + (size_t)N * Q * I * 2;
+    // ---- feed-forward, query rows: out = LN(pre3), pre3 = f Woq^T + b + fq ----
+    {
+      LnBwdArgs a{};
+      a.dy = dh; a.dyv = q_view; a.x = b.pre3; a.xv = q_view; a.gamma = W.lnqg; a.eps = c.ln_eps; a.rows = N * Q;
+      a.dx = t.dpre32; a.dxv = qc_rows; a.dx16 = t.dpre16; a.dx16v = qc_rows;
+      a.dgamma = G(p + "output_query.LayerNorm.weight"); a.dbeta = G(p + "output_query.LayerNorm.bias");
+      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-q ln bwd");
+    }
+    if ((rc = X.wgrad(t.dpre16, qc_rows, 64, b.f16, plain(N * Q, I), N * Q, H, I, G(p + "output_query.dense.weight"), G(p + "output_query.dense.bias"))))
+      return chk(rc, "dWoq");
+    if ((rc = X.gemm(t.dpre16, qc_rows, W.woqT, nullptr, t.dff16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_OP))) return chk(rc, "dff-q");
+    if ((rc = launch_gelu(b.u16, t.dff16, t.dff16, (long long)N * Q * I, 1, op, stream))) return chk(rc, "gelu bwd q");
+    if ((rc = X.wgrad(t.dff16, plain(N * Q, I), 64, fq16, fqv, N * Q, I, H, G(p + "intermediate_query.dense.weight"), G(p + "intermediate_query.dense.bias"))))
+      return chk(rc, "dWiq");
+    // d(fq) = d_pre3 (residual) + du Wiq  -> compact dhc32 (cross layers) or the query rows of dh1
+    float* dfq = W.cross_index >= 0 ? t.dhc32 : dh1;
+    const RowView dfqv = W.cross_index >= 0 ? qc_rows : q_view;
+    if ((rc = X.gemm(t.dff16, plain(N * Q, I), W.wiqT, nullptr, dfq, dfqv, t.dpre32, qc_rows, N * Q, H, I, EPI_RES_F32))) return chk(rc, "d_fq");
+    // ---- feed-forward, text rows ----
+    if (L > 0) {
+      LnBwdArgs a{};
+      a.dy = dh + t32; a.dyv = t_view; a.x = b.pre3 + t32; a.xv = t_view; a.gamma = W.lntg; a.eps = c.ln_eps; a.rows = N * L;
+      a.dx = t.dpre32 + (size_t)N * Q * H; a.dxv = plain(N * L, H); a.dx16 = t.dpre16 + (size_t)N * Q * H * 2; a.dx16v = plain(N * L, H);
+      a.dgamma = G(p + "output.LayerNorm.weight"); a.dbeta = G(p + "output.LayerNorm.bias");
+      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-t ln bwd");
+      const char* dpt16 = t.dpre16 + (size_t)N * Q * H * 2;
+      const float* dpt32 = t.dpre32 + (size_t)N * Q * H;
+      if ((rc = X.wgrad(dpt16, plain(N * L, H), 64, f_t, plain(N * L, I), N * L, H, I, G(p + "output.dense.weight"), G(p + "output.dense.bias")))) return chk(rc, "dWot");
+      if ((rc = X.gemm(dpt16, plain(N * L, H), W.wotT, nullptr, dff_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_OP))) return chk(rc, "dff-t");
+      if ((rc = launch_gelu(u_t, dff_t, dff_t, (long long)N * L * I, 1, op, stream))) return chk(rc, "gelu bwd t");
+      if ((rc = X.wgrad(dff_t, plain(N * L, I), 64, b.h1_16 + t16, t_view, N * L, I, H, G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"))))
+        return chk(rc, "dWit");
+      if ((rc = X.gemm(dff_t, plain(N * L, I), W.witT, nullptr, dh1 + t32, t_view, dpt32, plain(N * L, H), N * L, H, I, EPI_RES_F32))) return chk(rc, "d_h1t");
+    }
+    // ---- cross-attention block: hc = LN(pre2), pre2 = cctx Wco^T + b + h1[:, :32] ----
+    if (W.cross_index >= 0) {
+      LnBwdArgs a{};
+      a.dy = t.dhc32; a.dyv = qc_rows; a.x = b.pre2; a.xv = qc_rows; a.gamma = W.lncg; a.eps = c.ln_eps; a.rows = N * Q;
+      a.dx = t.dpre2_32; a.dxv = qc_rows; a.dx16 = t.dpre2_16; a.dx16v = qc_rows;
+      a.dgamma = G(p + "crossattention.output.LayerNorm.weight"); a.dbeta = G(p + "crossattention.output.LayerNorm.bias");
+      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "cross ln bwd");
+      if ((rc = X.wgrad(t.dpre2_16, qc_rows, 64, b.cctx16, qc_rows, N * Q, H, H, G(p + "crossattention.output.dense.weight"), G(p + "crossattention.output.dense.bias"))))
+        return chk(rc, "dWco");
+      if ((rc = X.gemm(t.dpre2_16, qc_rows, W.wcoT, nullptr, t.dcctx16, qc_rows, nullptr, qc_rows, N * Q, H, H, EPI_OP))) return chk(rc, "d_cctx");
+      AttnBwdArgs g{};
+      const size_t per_sel = (size_t)N * c.heads * kv * 64;
+      g.Q = b.qc16; g.K = t.kv16 + (size_t)(W.cross_index * 2) * per_sel * 2; g.V = t.kv16 + (size_t)(W.cross_index * 2 + 1) * per_sel * 2;
+      g.O = b.cctx16; g.dO = t.dcctx16;
+      g.dQ = t.dqc16; g.dK = t.dkv16 + (size_t)(W.cross_index * 2) * per_sel * 2; g.dV = t.dkv16 + (size_t)(W.cross_index * 2 + 1) * per_sel * 2;
+      g.q_item_stride = g.o_item_stride = g.dq_item_stride = (long long)Q * H; g.q_ld = g.o_ld = g.dq_ld = H;
+      g.k_item_stride = g.v_item_stride = g.dk_item_stride = g.dv_item_stride = (long long)c.heads * kv * 64;
+      g.k_head_stride = g.v_head_stride = g.dk_head_stride = g.dv_head_stride = (long long)kv * 64;
+      g.k_ld = g.v_ld = g.dk_ld = g.dv_ld = 64;
+      g.lse = b.lse_c; g.items = N; g.heads = c.heads; g.q_rows = Q; g.kv_len = kv; g.scale = 0.125f;
+      if ((rc = launch_attn_bwd(g, op, stream))) return chk(rc, "cross attention bwd");
+      if ((rc = X.wgrad(t.dqc16, qc_rows, 64, b.h1_16, q_view, N * Q, H, H, G(p + "crossattention.self.query.weight"), G(p + "crossattention.self.query.bias"))))
+        return chk(rc, "dWcq");
+      if ((rc = X.gemm(t.dqc16, qc_rows, W.wcqT, nullptr, dh1, q_view, t.dpre2_32, qc_rows, N * Q, H, H, EPI_RES_F32))) return chk(rc, "d_h1q");
+    }
+    // ---- self-attention block: h1 = LN(pre1), pre1 = ctx Wo^T + b + hin ----
+    {
+      LnBwdArgs a{};
+      a.dy = dh1; a.dyv = all_rows; a.x = b.pre1; a.xv = all_rows; a.gamma = W.ln1g; a.eps = c.ln_eps; a.rows = N * S;
+      a.dx = t.dpre32; a.dxv = all_rows; a.dx16 = t.dpre16; a.dx16v = all_rows;
+      a.dgamma = G(p + "attention.output.LayerNorm.weight"); a.dbeta = G(p + "attention.output.LayerNorm.bias");
+      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "attn ln bwd");
+    }
+    if ((rc = X.wgrad(t.dpre16, all_rows, 64, b.ctx16, all_rows, N * S, H, H, G(p + "attention.output.dense.weight"), G(p + "attention.output.dense.bias"))))
+      return chk(rc, "dWo");
+    if ((rc = X.gemm(t.dpre16, all_rows, W.woT, nullptr, t.dctx16, all_rows, nullptr, all_rows, N * S, H, H, EPI_OP))) return chk(rc, "d_ctx");
+    {
+      AttnBwdArgs g{};
+      g.Q = b.qkv16; g.K = b.qkv16 + (size_t)H * 2; g.V = b.qkv16 + (size_t)2 * H * 2; g.O = b.ctx16; g.dO = t.dctx16;
+      g.dQ = t.dqkv16; g.dK = t.dqkv16 + (size_t)H * 2; g.dV = t.dqkv16 + (size_t)2 * H * 2;
+      g.q_item_stride = g.k_item_stride = g.v_item_stride = g.dq_item_stride = g.dk_item_stride = g.dv_item_stride = (long long)S * 3 * H;
+      g.q_ld = g.k_ld = g.v_ld = g.dq_ld = g.dk_ld = g.dv_ld = 3 * H;
+      g.k_head_stride = g.v_head_stride = g.dk_head_stride = g.dv_head_stride = 64;
+      g.o_item_stride = SH; g.o_ld = H;
+      g.mask = (const long long*)attention_mask; g.mask_ld = S; g.lse = b.lse_s;
+      g.items = N; g.heads = c.heads; g.q_rows = S; g.kv_len = S; g.scale = 0.125f;
+      if ((rc = launch_attn_bwd(g, op, stream))) return chk(rc, "self attention bwd");
+    }
+    const char* names[3] = {"query", "key", "value"};
+    for (int j = 0; j < 3; ++j)
+      if ((rc = X.wgrad(t.dqkv16 + (size_t)j * H * 2, plain(N * S, 3 * H), 64, b.hin16, all_rows, N * S, H, H,
+                        G(p + "attention.self." + names[j] + ".weight"), G(p + "attention.self." + names[j] + ".bias"))))
+        return chk(rc, "dWqkv");
+    // gradient w.r.t. the layer input: d_pre1 (residual) + dqkv Wqkv  -> becomes dh of layer i-1
+    if ((rc = X.gemm(t.dqkv16, plain(N * S, 3 * H), W.wqkvT, nullptr, dh, all_rows, t.dpre32, all_rows, N * S, H, 3 * H, EPI_RES_F32))) return chk(rc, "d_hin");
+  }
+  // ---- embeddings: h0 = LN(emb_pre) ----
+  {
+    LnBwdArgs a{};
+    a.dy = dh; a.dyv = all_rows; a.x = t.emb_pre; a.xv = all_rows; a.gamma = h->embg; a.eps = c.ln_eps; a.rows = N * S;
+    a.dx = t.dpre32; a.dxv = all_rows;
+    a.dgamma = G("bert.embeddings.LayerNorm.weight"); a.dbeta = G("bert.embeddings.LayerNorm.bias");
+    if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "embedding ln bwd");
+    if ((rc = launch_embed_bwd(t.dpre32, (const long long*)input_ids, N, L, Q, H, c.vocab, G("query_tokens"), G("bert.embeddings.position_embeddings.weight"),
+                               G("bert.embeddings.word_embeddings.weight"), stream)))
+      return chk(rc, "embedding bwd");
+  }
+  // ---- cross K/V projections: dWk / dWv of every cross layer from the head-major dK / dV cache ----
+  for (int i = 0; i < c.layers; ++i) {
+    const int cl = h->layers[i].cross_index;
+    if (cl < 0) continue;
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".crossattention.self.";
+    const size_t per_sel = (size_t)N * c.heads * kv * 64;
+    const RowView hv = items_view((long long)c.heads * kv * 64, kv, 64);
+    for (int kvsel = 0; kvsel < 2; ++kvsel) {
+      const char* dY = t.dkv16 + (size_t)(cl * 2 + kvsel) * per_sel * 2;
+      const std::string nm = p + (kvsel ? "value" : "key");
+      if ((rc = X.wgrad(dY, hv, (long long)kv * 64, enc, plain(N * kv, c.enc_width), N * kv, H, c.enc_width, G(nm + ".weight"), G(nm + ".bias"))))
+        return chk(rc, "dWkv");
+    }
+  }
+  return MRA_OK;
+}
+
+}  // extern "C"

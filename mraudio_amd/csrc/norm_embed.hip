@@ -161,7 +161,7 @@ template <typename T, int NV>
 __global__ void __launch_bounds__(256) embed_ln_kernel(const long long* ids, int items, int L, int Q, int vocab,
                                                        const float* query, long long qstride, const float* word, const float* pos,
                                                        const float* gain, const float* bias, float eps, float* h32,
-                                                       T* h16) {
+                                                       T* h16, float* pre32) {
   constexpr int H = NV * 256;
   const int lane = threadIdx.x & 63;
   const int S = Q + L;
@@ -184,6 +184,10 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const long long* ids, int
       const int c = (i * 64 + lane) * 4;
       v[i] = *reinterpret_cast<const f32x4*>(wr + c) + *reinterpret_cast<const f32x4*>(pr + c);
     }
+  }
+  if (pre32) {  // training: the pre-LayerNorm embedding row is needed by the backward
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(pre32 + row * H + (i * 64 + lane) * 4) = v[i];
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -306,14 +310,14 @@ int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, 
 
 int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vocab, const float* query,
                     long long query_item_stride, const float* word, const float* pos, const float* gain, const float* bias, float eps, float* h32,
-                    void* h16, int op_dtype, hipStream_t stream) {
+                    void* h16, float* pre32, int op_dtype, hipStream_t stream) {
   if (items <= 0) return 0;
   if (H % 256 || H > 1024 || H <= 0 || L < 0 || Q < 0) return -1;
   const long long rows = (long long)items * (Q + L);
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define MRA_EM_CASE(T, NV)                                                                                        \
   hipLaunchKernelGGL((embed_ln_kernel<T, NV>), grid, block, 0, stream, ids, items, L, Q, vocab, query, query_item_stride, word, pos, \
-                     gain, bias, eps, h32, (T*)h16)
+                     gain, bias, eps, h32, (T*)h16, pre32)
   const int nv = H / 256;
   if (op_dtype == OP_F16) {
     if (nv == 1) MRA_EM_CASE(f16, 1); else if (nv == 2) MRA_EM_CASE(f16, 2); else if (nv == 3) MRA_EM_CASE(f16, 3); else MRA_EM_CASE(f16, 4);

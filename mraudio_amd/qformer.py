@@ -230,6 +230,11 @@ class QFormer(nn.Module):
                                          current_stream()), f"mra_qformer_load({name})")
 
     def sync_weights(self) -> None:
+        # in-place updates (an optimizer step) bump the tensors' version counters
+        ver = sum(p._version for p in self.bert.parameters())
+        if ver != getattr(self, "_param_version", None):
+            self._param_version = ver
+            self._dirty = True
         if not self._dirty:
             return
         for k, v in self.bert.state_dict(prefix="bert.").items():
@@ -337,3 +342,104 @@ class QFormer(nn.Module):
 
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
         return float(lib().mra_qformer_flops(self._handle, items, L, kv, int(with_last_text)))
+
+
+# --------------------------------------------------------------------------------------------------
+# training (BASELINE config 5): forward with an activation tape + HIP backward behind torch.autograd
+# --------------------------------------------------------------------------------------------------
+class _QFormerTrainFn(torch.autograd.Function):
+    """Autograd node around ``mra_qformer_forward_train`` / ``mra_qformer_backward``.  The parameters
+    live inside the handle, so the node takes an anchor tensor that requires grad; its backward runs the
+    HIP backward, which ADDS into the owner's flat f32 gradient buffer (``QFormer.grad_of``)."""
+
+    @staticmethod
+    def forward(ctx, anchor, owner, input_ids, attention_mask, enc, want_cls):
+        cfg = owner.cfg
+        N, Kv = int(enc.shape[0]), int(enc.shape[1])
+        L = 0 if input_ids is None else int(input_ids.shape[1])
+        dev = enc.device
+        out_q = torch.empty(N, cfg.n_query, cfg.hidden, dtype=torch.float32, device=dev)
+        out_c = torch.empty(N, cfg.hidden, dtype=torch.float32, device=dev) if want_cls else None
+        with torch.cuda.device(dev):
+            nbytes = int(lib().mra_qformer_train_workspace_bytes(owner._handle, N, L, Kv))
+            if owner._train_ws is None or owner._train_ws.numel() < nbytes:
+                owner._train_ws = None
+                owner._train_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            check(lib().mra_qformer_forward_train(owner._handle, ptr(input_ids), ptr(attention_mask), ptr(enc), N, L, Kv, ptr(out_q),
+                                                  ptr(out_c), ptr(owner._train_ws), owner._train_ws.numel(), current_stream()),
+                  "mra_qformer_forward_train")
+        ctx.owner, ctx.shape = owner, (N, L, Kv)
+        ctx.save_for_backward(input_ids, attention_mask, enc)
+        ctx.want_cls = want_cls
+        return (out_q, out_c) if want_cls else (out_q, torch.empty(0, device=dev))
+
+    @staticmethod
+    def backward(ctx, d_q, d_c):
+        owner = ctx.owner
+        input_ids, attention_mask, enc = ctx.saved_tensors
+        N, L, Kv = ctx.shape
+        d_q = None if d_q is None else d_q.to(torch.float32).contiguous()
+        d_c = d_c.to(torch.float32).contiguous() if (ctx.want_cls and d_c is not None) else None
+        owner._run_backward(input_ids, attention_mask, enc, N, L, Kv, d_q, d_c)
+        return torch.zeros_like(owner._anchor), None, None, None, None, None
+
+
+def _qformer_enable_training(self: "QFormer") -> None:
+    """Allocate the flat gradient buffer, bind every ``bert.*`` parameter's ``.grad`` to its slice and build
+    the transposed weight copies (call again after changing weights; ``forward_train`` does it lazily)."""
+    self.sync_weights()
+    with torch.cuda.device(self._device):
+        check(lib().mra_qformer_enable_training(self._handle, current_stream()), "mra_qformer_enable_training")
+    if getattr(self, "_grad_flat", None) is None:
+        n = int(lib().mra_qformer_grad_bytes(self._handle)) // 4
+        self._grad_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
+        self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
+        self._train_ws = None
+        for p in self.bert.parameters():
+            p.requires_grad_(True)
+
+
+def _qformer_grad_of(self: "QFormer", name: str) -> torch.Tensor:
+    """View of parameter ``name``'s gradient inside the flat buffer (ABI names, e.g. ``query_tokens``)."""
+    off, numel = C.c_size_t(), C.c_int64()
+    check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
+    return self._grad_flat[off.value // 4: off.value // 4 + numel.value]
+
+
+def _qformer_bind_grads(self: "QFormer") -> None:
+    for k, p in self.bert.state_dict(prefix="bert.", keep_vars=True).items():
+        if p.grad is None or p.grad.data_ptr() != self.grad_of(k).data_ptr():
+            p.grad = self.grad_of(k).view_as(p)
+
+
+def _qformer_forward_train(self: "QFormer", input_ids, attention_mask, enc, want_cls: bool = True):
+    """Training forward: ``(out_query [N,32,H], out_cls [N,H])`` connected to autograd.  ``loss.backward()``
+    accumulates parameter gradients (``p.grad`` of every ``bert.*`` parameter, ``grad_of('query_tokens')``)."""
+    self.enable_training()
+    cfg = self.cfg
+    enc = enc.to(cfg.op_dtype).contiguous()
+    if input_ids is not None:
+        input_ids = input_ids.to(device=enc.device, dtype=torch.int64).contiguous()
+    if attention_mask is not None:
+        attention_mask = attention_mask.to(device=enc.device, dtype=torch.int64).contiguous()
+    q, c = _QFormerTrainFn.apply(self._anchor, self, input_ids, attention_mask, enc, want_cls)
+    return (q, c) if want_cls else (q, None)
+
+
+def _qformer_run_backward(self: "QFormer", input_ids, attention_mask, enc, N, L, Kv, d_q, d_c) -> None:
+    # optimizer.zero_grad(set_to_none=True) drops the views: start from a clean buffer in that case
+    probe = self.bert.embeddings.LayerNorm.weight
+    if probe.grad is None:
+        self._grad_flat.zero_()
+    with torch.cuda.device(self._device):
+        check(lib().mra_qformer_backward(self._handle, ptr(input_ids), ptr(attention_mask), ptr(enc), N, L, Kv, ptr(d_q), ptr(d_c),
+                                         ptr(self._grad_flat), ptr(self._train_ws), self._train_ws.numel(), current_stream()),
+              "mra_qformer_backward")
+    self._bind_grads()
+
+
+QFormer.enable_training = _qformer_enable_training
+QFormer.grad_of = _qformer_grad_of
+QFormer._bind_grads = _qformer_bind_grads
+QFormer.forward_train = _qformer_forward_train
+QFormer._run_backward = _qformer_run_backward

@@ -445,7 +445,7 @@ static void test_embed() {
   Dev<float> dq(query), dw(word), dp(pos), dg(g), db(b), dh((size_t)items * (Q + L) * H);
   Dev<uint16_t> dh16((size_t)items * (Q + L) * H);
   Dev<long long> dids(ids);
-  int rc = launch_embed_ln(dids.p, items, L, Q, H, vocab, dq.p, 0, dw.p, dp.p, dg.p, db.p, 1e-12f, dh.p, dh16.p, OP_F16, 0);
+  int rc = launch_embed_ln(dids.p, items, L, Q, H, vocab, dq.p, 0, dw.p, dp.p, dg.p, db.p, 1e-12f, dh.p, dh16.p, nullptr, OP_F16, 0);
   CK(hipDeviceSynchronize());
   std::vector<float> h = dh.get();
   double worst = rc ? 1e30 : 0;

@@ -1,0 +1,128 @@
+"""BASELINE config 5 (``-m gpu``): Q-Former forward + backward on the HIP path against torch.autograd over
+the CPU oracle.  The reference never trains its Q-Formers (frozen, models/xinstructblip.py:196-204), so
+the oracle's autograd IS the definition of correct here.
+
+Tolerance: both passes feed f16 operands to the MFMAs with fp32 accumulation; a gradient tensor must
+agree with the fp32 oracle to 2e-2 in relative Frobenius norm (measured ~3e-3) and no element may be off
+by more than 5 % of the tensor's largest entry.
+"""
+import pytest
+import torch
+
+from oracle import qformer_ref as O
+from tools.make_golden import make_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _setup(dev, enc_width, seed):
+    from mraudio_amd.qformer import QFormer, QFormerConfig, draw_seeded
+
+    cfg = QFormerConfig(enc_width=enc_width)
+    qf = QFormer(cfg, device=dev)
+    g = qf.init_seeded_(seed=seed, perturb=True)
+    qt = draw_seeded(g, (1, cfg.n_query, cfg.hidden), "w", True)
+    qf.push("query_tokens", qt)
+    qf.push("ln.weight", draw_seeded(g, (enc_width,), "g", True))
+    qf.push("ln.bias", draw_seeded(g, (enc_width,), "z", True))
+    ocfg = O.QFormerCfg(enc_width=enc_width)
+    w = O.init_weights(ocfg, seed=seed, perturb=True)
+    return qf, cfg, ocfg, w
+
+
+def test_forward_backward_matches_oracle_autograd(dev):
+    qf, cfg, ocfg, w = _setup(dev, 1408, 0)
+    n, L, kv = 4, 9, 40
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 77, True)
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).half()   # the exact operand the kernels see
+    g = torch.Generator().manual_seed(5)
+    rq, rc = torch.randn(n, 32, 768, generator=g), torch.randn(n, 768, generator=g)
+
+    # oracle: fp32 autograd
+    wl = {k: (v.clone().requires_grad_(True) if k.startswith("bert.") or k == "query_tokens" else v) for k, v in w.items()}
+    h = O.qformer_forward(wl, ocfg, ids, att, wl["query_tokens"].expand(n, -1, -1), enc.float())
+    loss_ref = (h[:, :32] * rq).sum() + (h[:, 32] * rc).sum()
+    loss_ref.backward()
+
+    # HIP path
+    q, c = qf.forward_train(ids.to(dev), att.to(dev), enc.to(dev))
+    assert (q.cpu() - h[:, :32].detach()).abs().max().item() < 1e-2
+    assert (c.cpu() - h[:, 32].detach()).abs().max().item() < 1e-2
+    inf = qf.forward_fused(ids.to(dev), att.to(dev), enc.to(dev), want_query=True, want_cls=True)
+    assert (inf["query"] - q).abs().max().item() < 1e-2          # training keeps the pre-GELU value in f16 (one more rounding)
+    loss = (q * rq.to(dev)).sum() + (c * rc.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    worst, worst_name = 0.0, ""
+    for k, ref in wl.items():
+        if not (k.startswith("bert.") or k == "query_tokens"):
+            continue
+        gref = ref.grad
+        got = qf.grad_of(k).view_as(gref).cpu()
+        if k == "bert.embeddings.word_embeddings.weight":
+            assert torch.count_nonzero(got).item() > 0
+        denom = gref.norm().item()
+        if k.endswith("key.bias"):
+            # softmax is invariant to a per-query shift of the scores, so the true key-bias gradient is 0 (the
+            # oracle's value is fp32 noise): the kernel's must be noise too, measured against the query-bias one
+            scale = wl[k.replace(".key.", ".query.")].grad.norm().item()
+            assert got.norm().item() < 2e-2 * scale + 1e-4, (k, got.norm().item(), scale)
+            continue
+        rel = ((got - gref).norm() / denom).item()
+        peak = (got - gref).abs().max().item() / gref.abs().max().item()
+        if rel > worst:
+            worst, worst_name = rel, k
+        assert rel < 2e-2 and peak < 5e-2, (k, rel, peak)
+    print("worst relative gradient error", worst, worst_name)
+    # parameter .grad fields are views of the flat buffer
+    p = qf.bert.encoder.layer[3].attention.output.dense.weight
+    assert p.grad is not None and p.grad.data_ptr() == qf.grad_of("bert.encoder.layer.3.attention.output.dense.weight").data_ptr()
+
+
+def test_gradient_accumulation_and_zeroing(dev):
+    qf, cfg, ocfg, w = _setup(dev, 768, 1)
+    n, L, kv = 2, 5, 24
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 3, False)
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).half().to(dev)
+    key = "bert.encoder.layer.0.crossattention.self.value.weight"
+
+    def run():
+        q, c = qf.forward_train(ids.to(dev), att.to(dev), enc)
+        (q.sum() + c.sum()).backward()
+
+    run()
+    g1 = qf.grad_of(key).clone()
+    run()                                            # second micro-batch accumulates (utils/trainer.py:31,137 grad-accum 2)
+    assert torch.allclose(qf.grad_of(key), 2 * g1, rtol=1e-3, atol=1e-5)
+    for p in qf.bert.parameters():                   # what optimizer.zero_grad(set_to_none=True) does
+        p.grad = None
+    run()
+    assert torch.allclose(qf.grad_of(key), g1, rtol=1e-3, atol=1e-5)
+
+
+def test_one_training_step_moves_the_loss(dev):
+    """fwd + bwd + Adam on the Q-Former parameters: the loss of the same batch must drop."""
+    qf, cfg, ocfg, w = _setup(dev, 768, 2)
+    n, L, kv = 4, 6, 32
+    ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 9, False)
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).half().to(dev)
+    target = torch.randn(n, 32, 768, generator=torch.Generator().manual_seed(1)).to(dev)
+    qf.enable_training()
+    params = [p for k, p in qf.bert.named_parameters() if "word_embeddings" not in k]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=False)
+        q, _ = qf.forward_train(ids.to(dev), att.to(dev), enc, want_cls=False)
+        loss = torch.nn.functional.mse_loss(q, target)
+        loss.backward()
+        opt.step()                                   # in-place update; the next forward re-uploads the weights
+        losses.append(loss.item())
+    assert losses[2] < losses[0], losses
