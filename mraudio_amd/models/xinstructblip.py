@@ -245,6 +245,11 @@ class XInstructBLIP(nn.Module):
         return self._streams[modality]
 
     def _sync(self):
+        ver = sum(getattr(self, f"{m}_{n}")._version if n == "query_tokens" else sum(p._version for p in getattr(self, f"{m}_{n}").parameters())
+                  for m in self.modalities for n in ("query_tokens", "ln", "llm_proj"))
+        if ver != getattr(self, "_extras_version", None):
+            self._extras_version = ver
+            self._extras_dirty = True
         for m in self.modalities:
             qf: QFormer = getattr(self, f"{m}_Qformer")
             qf.sync_weights()
@@ -385,15 +390,8 @@ class XInstructBLIP(nn.Module):
         ts = [t.tolist() if torch.is_tensor(t) else list(t) for t in ts]
         return [o.strip() for o in scorer.spans_to_text(spans, ts)]
 
-    def forward(self, samples):
-        """Reference ``:399-606`` returns the LLM's cross-entropy.  Without an LLM on this path the
-        training signal is build-defined: binary cross-entropy between sigmoid(20 * fused logit) and
-        clip membership of the target span parsed from ``text_output``.  Forward only (the Q-Former is
-        frozen in the reference, ``:196-204``; backward kernels are a later row)."""
-        if samples is None or samples == {} or not any(m in samples or f"{m}_embeds" in samples for m in self.modalities):
-            return {"loss": torch.tensor(0.0)}
-        out = self.encode_fuse(samples)
-        bs, num = out["bs"], out["num"]
+    def _targets(self, samples, bs, num):
+        """Clip-membership targets of the spans in ``samples["text_output"]`` (``"[[s, e]]"`` seconds)."""
         target = torch.zeros(bs, num, dtype=torch.float32, device=self._device)
         ts = samples.get("timestamps") or [list(range(num))] * bs
         for r, txt in enumerate(samples.get("text_output", ["[[-1, -1]]"] * bs)):
@@ -401,8 +399,66 @@ class XInstructBLIP(nn.Module):
             if len(nums) == 2 and nums[0] >= 0:
                 t = torch.as_tensor(ts[r], dtype=torch.float32, device=self._device)
                 target[r] = ((t >= nums[0]) & (t <= nums[1])).float()
-        logits = out["fused"].view(bs, num) * 20.0
-        return {"loss": nn.functional.binary_cross_entropy_with_logits(logits, target)}
+        return target
+
+    def enable_qformer_training(self) -> None:
+        """Unfreeze the Q-Formers (the reference keeps them frozen, ``:196-204``; BASELINE config 5 trains
+        them): parameters get ``requires_grad`` and gradients from the HIP backward."""
+        self.train_qformers = True
+        for m in self.modalities:
+            qf: QFormer = getattr(self, f"{m}_Qformer")
+            qf.enable_training()
+            qt = getattr(self, f"{m}_query_tokens")
+            qt.requires_grad_(True)
+            qf._extra_grad_binder = (lambda qf=qf, qt=qt: setattr(qt, "grad", qf.grad_of("query_tokens").view_as(qt)))
+
+    def forward(self, samples):
+        """Reference ``:399-606`` returns the LLM's cross-entropy.  Without an LLM on this path the
+        training signal is build-defined: binary cross-entropy between sigmoid(20 * fused logit) and clip
+        membership of the target span parsed from ``text_output``.  After ``enable_qformer_training()`` the
+        loss is differentiable w.r.t. every Q-Former parameter (forward + backward on the HIP extension; the
+        few-KB scorer and the loss run as torch ops so autograd can seed the backward); otherwise it is a
+        forward-only value, as the reference's frozen Q-Formers would give."""
+        if samples is None or samples == {} or not any(m in samples or f"{m}_embeds" in samples for m in self.modalities):
+            return {"loss": torch.tensor(0.0)}
+        if not getattr(self, "train_qformers", False):
+            out = self.encode_fuse(samples)
+            bs, num = out["bs"], out["num"]
+            logits = out["fused"].view(bs, num) * 20.0
+            return {"loss": nn.functional.binary_cross_entropy_with_logits(logits, self._targets(samples, bs, num))}
+        self._sync()
+        text = self.tokenizer(samples["text_input"], padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
+        ids, tmask = text.input_ids.to(self._device), text.attention_mask.to(self._device)
+        per_mod, bs, num = [], None, None
+        for m in self.modalities:
+            if m not in samples and f"{m}_embeds" not in samples:
+                continue
+            qf: QFormer = getattr(self, f"{m}_Qformer")
+            with torch.no_grad():
+                raw, idx, bs, num = self._encode(samples, m)
+                enc = qf.modality_ln(raw, item_index=idx, items=bs * num)
+            n = bs * num
+            ids_n, tm_n = (ids.repeat(num, 1), tmask.repeat(num, 1)) if self.compat_repeat else \
+                          (ids.repeat_interleave(num, 0), tmask.repeat_interleave(num, 0))
+            att = torch.cat([torch.ones(n, self.num_query_token, dtype=torch.long, device=self._device), tm_n], dim=1)
+            z, cls = qf.forward_train(ids_n, att, enc)
+            sim = nn.functional.cosine_similarity(z, cls[:, None, :], dim=-1, eps=1e-8)
+            per_mod.append(sim.max(dim=1).values)
+        w = self.fuse_weights or [1.0 / len(per_mod)] * len(per_mod)
+        fused = sum(x * wt for x, wt in zip(per_mod, w))
+        return {"loss": nn.functional.binary_cross_entropy_with_logits(fused.view(bs, num) * 20.0, self._targets(samples, bs, num))}
+
+    def all_reduce_grads(self) -> None:
+        """Data-parallel gradient averaging over the process group: one all-reduce of each Q-Former's flat f32
+        gradient buffer (what DDP does bucket by bucket in the reference's trainer, ``utils/trainer.py:69,133``)."""
+        rank, ws = parallel.world(self.process_group)
+        if ws == 1:
+            return
+        import torch.distributed as dist
+        for m in self.modalities:
+            flat = getattr(self, f"{m}_Qformer")._grad_flat
+            dist.all_reduce(flat, group=self.process_group)
+            flat.div_(ws)
 
 
 def _ref(obj):

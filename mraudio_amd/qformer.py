@@ -436,6 +436,9 @@ def _qformer_run_backward(self: "QFormer", input_ids, attention_mask, enc, N, L,
                                          ptr(self._grad_flat), ptr(self._train_ws), self._train_ws.numel(), current_stream()),
               "mra_qformer_backward")
     self._bind_grads()
+    binder = getattr(self, "_extra_grad_binder", None)
+    if binder is not None:
+        binder()
 
 
 QFormer.enable_training = _qformer_enable_training

@@ -126,3 +126,40 @@ def test_one_training_step_moves_the_loss(dev):
         opt.step()                                   # in-place update; the next forward re-uploads the weights
         losses.append(loss.item())
     assert losses[2] < losses[0], losses
+
+
+def test_model_level_finetune_step(dev):
+    """finetune.py-shaped use (utils/trainer.py:124-140): loss = model(samples)["loss"]; loss.backward();
+    optimizer.step() -- on a Charades-STA-shaped synthetic batch (B = 1, T = 20), both modalities."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    model = XInstructBLIP(seed=3, perturb=True, device=dev)
+    model.enable_qformer_training()
+    g = torch.Generator().manual_seed(2)
+    samples = {"video_embeds": torch.randn(1, 20, 257, 1408, generator=g), "audio_embeds": torch.randn(1, 20, 256, 768, generator=g),
+               "text_input": ["Query: a person opens the door.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
+               "text_output": ["[[6, 12]]"], "timestamps": [list(range(0, 40, 2))], "duration": [40]}
+    params = [p for d in model.get_optimizer_params(0.05) for p in d["params"]]
+    assert len(params) > 500 and all(p.requires_grad for p in params)
+    params = [p for p in params if p.shape[0] != 30523]   # leave the word embeddings out of Adam (sparse rows)
+    opt = torch.optim.SGD(params, lr=1.0)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss = model(samples)["loss"]
+        loss.backward()
+        model.all_reduce_grads()
+        assert model.video_query_tokens.grad is not None and torch.isfinite(model.video_query_tokens.grad).all()
+        assert torch.isfinite(model.audio_Qformer._grad_flat).all()
+        # a fixed-length step along the negative gradient (length 0.05 in parameter space): if the gradients are
+        # right the loss of the same batch must go down to first order
+        gnorm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params)).item()
+        assert gnorm > 0
+        for grp in opt.param_groups:
+            grp["lr"] = 0.05 / gnorm
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] and losses[1] < losses[0], losses
+    # inference after training uses the updated weights
+    out = model.generate(samples)
+    assert len(out) == 1 and out[0].startswith("[[")

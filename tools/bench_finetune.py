@@ -1,0 +1,75 @@
+"""Times BASELINE config 5: a finetune.py-shaped step with the Q-Formers unfrozen -- forward with tape,
+backward, gradient all-reduce, Adam, weight re-upload -- on a synthetic Charades-STA-shaped batch
+(B = 1 video, T = 20 positions, 257 ViT-g + 256 BEATs tokens per position, L = 32-ish prompt tokens).
+Beyond the reference (its Q-Formers are frozen); not the bench.py headline.
+
+    python tools/bench_finetune.py [--steps 10] [--dtype bf16]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_finetune.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    args = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    model = XInstructBLIP(seed=0, perturb=False, op_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16, device=dev)
+    model.enable_qformer_training()
+    g = torch.Generator().manual_seed(100 + rank)
+    samples = {"video_embeds": torch.randn(1, 20, 257, 1408, generator=g).to(dev), "audio_embeds": torch.randn(1, 20, 256, 768, generator=g).to(dev),
+               "text_input": ["Query: a person opens the door and walks in.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
+               "text_output": ["[[6, 12]]"], "timestamps": [list(range(0, 40, 2))], "duration": [40]}
+    params = [p for d in model.get_optimizer_params(0.05) for p in d["params"] if p.shape[0] != 30523]
+    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    t = {"fwd": 0.0, "bwd": 0.0, "allreduce": 0.0, "adam": 0.0}
+
+    def tick():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            for k in t:
+                t[k] = 0.0
+            if world > 1:
+                dist.barrier()
+            t_all = tick()
+        opt.zero_grad(set_to_none=True)
+        a = tick(); loss = model(samples)["loss"]
+        b = tick(); loss.backward()
+        c = tick(); model.all_reduce_grads()
+        d = tick(); opt.step()
+        e = tick()
+        t["fwd"] += b - a; t["bwd"] += c - b; t["allreduce"] += d - c; t["adam"] += e - d
+    if world > 1:
+        dist.barrier()
+    total = tick() - t_all
+    if rank == 0:
+        print(json.dumps({"config": "BASELINE config 5: Q-Former fwd+bwd finetune step, B=1 x T=20 per GPU, both modalities", "n_gpus": world,
+                          "dtype": args.dtype, "steps": args.steps, "ms_per_step": round(total / args.steps * 1e3, 2),
+                          "steps_per_s_per_gpu": round(args.steps / total, 2), "clips_per_s": round(20 * world * args.steps / total, 1),
+                          "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t.items()}, "loss": round(loss.item(), 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
