@@ -8,11 +8,15 @@
 // like the V tile of the attention kernel (128-byte rows, 16-byte chunk index XOR ((m >> 1) & 1) << 2 on
 // the source address) and both fragments come from ds_read_b64_tr_b16 transposed reads:
 //     D[32 n x 32 k] += A[32 n x 16 m] * B[16 m x 32 k],   v_mfma_f32_32x32x16, fp32 accumulate.
-// One workgroup = 64 n x 64 k (4 waves, one 32x32 tile each), double-buffered over m.  Gradient GEMMs
-// are small here (M = items * S ~ 1 k rows): this kernel is written for correctness and decent
-// occupancy, not for the roofline.
+// One workgroup = 64 n x 64 k (4 waves, one 32x32 tile each) over a three-deep ring of m tiles (two tiles
+// in flight behind the one being read, counted vmcnt, one barrier per step).  Gradient GEMMs are small
+// here (M = items * S ~ 1 k rows, 144 output tiles for a 768 x 768 weight): the launcher splits M over
+// blockIdx.z until the grid has ~512 workgroups and the partial tiles are added with fp32 atomics
+// (summation order across splits is not fixed; the gradient buffer is an accumulator anyway).
 #include "kernels.h"
 #include "mra_common.h"
+
+#include <algorithm>
 
 namespace mra {
 
@@ -66,12 +70,20 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int nsteps = (M + BMT - 1) / BMT;
-  issue(0, 0);
-  for (int st = 0; st < nsteps; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 1 < nsteps) issue((st + 1) & 1, (st + 1) * BMT);
-    const unsigned ybase = lds0 + (st & 1) * 2 * TILE_B + lane_off[ct_n];
+  const int per = (nsteps + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int s0 = blockIdx.z * per, s1 = min(nsteps, s0 + per);
+  if (s0 >= s1) return;                      // workgroup-uniform
+  issue(0, s0 * BMT);
+  if (s0 + 1 < s1) issue(1, (s0 + 1) * BMT);
+  int buf = 0;
+  for (int st = s0; st < s1; ++st) {
+    if (st + 1 < s1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + 2 < s1) issue(buf >= 1 ? buf - 1 : 2, (st + 2) * BMT);   // the tile read one step ago
+    const unsigned ybase = lds0 + buf * 2 * TILE_B + lane_off[ct_n];
+    buf = buf == 2 ? 0 : buf + 1;
     const unsigned xbase = ybase - lane_off[ct_n] + TILE_B + lane_off[ct_k];
     i16x4 ya0, ya1, ya2, ya3, xb0, xb1, xb2, xb3;
     asm volatile(
@@ -115,25 +127,40 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
   for (int r = 0; r < 16; ++r) {
     const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     float* p = out + (long long)n * a.ldw;
-    *p = a.accumulate ? *p + acc[r] : acc[r];
+    if (gridDim.z > 1) unsafeAtomicAdd(p, acc[r]);
+    else *p = a.accumulate ? *p + acc[r] : acc[r];
   }
 }
 
-// db[n] (+)= sum_m dY[m][n]; one wave per 64-column block, lanes = columns, 4 waves split the rows
+// db[n] (+)= sum_m dY[m][n].  Grid (N / 64, row chunks): a thread reads 16 bytes (8 columns) of one row, 32
+// rows per pass; the 32 row partials meet in LDS and one fp32 atomic per column and workgroup lands in db.
+constexpr int COLSUM_ROWS = 256;
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const void* dY_, long long block_stride, RowView yv, int M, float* db,
                                                      int accumulate) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* Y = (const T*)dY_ + (long long)blockIdx.x * block_stride + lane;
-  float s = 0.f;
-  for (int m = wave; m < M; m += 4) s += (float)Y[tn_row_off(yv, m)];
-  part[wave][lane] = s;
+  __shared__ float part[32][65];
+  const int tid = threadIdx.x, c8 = tid & 7, r = tid >> 3;
+  const T* Y = (const T*)dY_ + (long long)blockIdx.x * block_stride + c8 * 8;
+  const int m0 = blockIdx.y * COLSUM_ROWS, m1 = min(M, m0 + COLSUM_ROWS);
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll 4
+  for (int m = m0 + r; m < m1; m += 32) {
+    const typename Vec8<T>::type v = *(const typename Vec8<T>::type*)(Y + tn_row_off(yv, m));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[r][c8 * 8 + j] = s[j];
   __syncthreads();
-  if (wave == 0) {
-    const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    float* p = db + blockIdx.x * 64 + lane;
-    *p = accumulate ? *p + t : t;
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += part[i][tid];
+    float* p = db + blockIdx.x * 64 + tid;
+    if (gridDim.y > 1) unsafeAtomicAdd(p, t);
+    else *p = accumulate ? *p + t : t;
   }
 }
 
@@ -143,8 +170,15 @@ int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
   if (a.N % 64 || a.K % 64) return -1;
   if (a.yv.rpi <= 0 || a.xv.rpi <= 0 || (a.yv.ld & 7) || (a.xv.ld & 7)) return -1;
-  const dim3 grid(a.N / 64, a.K / 64), block(256);
-  const size_t lds = 4 * TILE_B;
+  const int tiles = (a.N / 64) * (a.K / 64), nsteps = (a.M + BMT - 1) / BMT;
+  int splits = (512 + tiles - 1) / tiles;
+  splits = std::max(1, std::min(splits, nsteps / 4));
+  if (splits > 1 && !a.accumulate) {
+    // partial tiles are added atomically: start from zero (dW rows may be strided by ldw)
+    if (hipMemset2DAsync(a.dW, (size_t)a.ldw * 4, 0, (size_t)a.K * 4, a.N, stream) != hipSuccess) return -4;
+  }
+  const dim3 grid(a.N / 64, a.K / 64, splits), block(256);
+  const size_t lds = 6 * TILE_B;
   if (op_dtype == OP_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -152,9 +186,11 @@ int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream) {
 
 int launch_colsum(const void* dY, long long block_stride, RowView yv, int M, int N, float* db, int accumulate, int op_dtype,
                   hipStream_t stream) {
-  if (M <= 0 || N <= 0 || N % 64 || yv.rpi <= 0) return -1;
-  if (op_dtype == OP_F16) hipLaunchKernelGGL(colsum_kernel<f16>, dim3(N / 64), dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
-  else hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(N / 64), dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
+  if (M <= 0 || N <= 0 || N % 64 || yv.rpi <= 0 || (yv.ld & 7)) return -1;
+  const dim3 grid(N / 64, (M + COLSUM_ROWS - 1) / COLSUM_ROWS);
+  if (grid.y > 1 && !accumulate && hipMemsetAsync(db, 0, (size_t)N * 4, stream) != hipSuccess) return -4;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
+  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, dY, block_stride, yv, M, db, accumulate);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
