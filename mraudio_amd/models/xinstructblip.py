@@ -127,6 +127,10 @@ class XInstructBLIP(nn.Module):
         self.score_alpha = score_alpha
         self.fuse_weights = fuse_weights
         self.process_group = process_group
+        # True: the clips of one batch are sharded over the ranks (inference, every rank is given the same
+        # samples).  False: ranks hold different samples (data-parallel training, utils/trainer.py) and only
+        # gradients are exchanged.
+        self.clip_parallel = True
         self.overlap_modalities = overlap_modalities
         self._streams: Dict[str, torch.cuda.Stream] = {}
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -239,6 +243,12 @@ class XInstructBLIP(nn.Module):
         return [{"params": decay, "weight_decay": weight_decay, "lr_scale": lr_scale},
                 {"params": no_decay, "weight_decay": 0, "lr_scale": lr_scale}]
 
+    def _clip_world(self):
+        return parallel.world(self.process_group) if self.clip_parallel else (0, 1)
+
+    def _gather(self, rows: torch.Tensor, n_total: int) -> torch.Tensor:
+        return parallel.all_gather_rows(rows, n_total, self.process_group) if self.clip_parallel else rows
+
     def _side_stream(self, modality: str) -> torch.cuda.Stream:
         if modality not in self._streams:
             self._streams[modality] = torch.cuda.Stream(device=self._device)
@@ -300,7 +310,7 @@ class XInstructBLIP(nn.Module):
         [CLS] vectors over the process group -> cosine score -> fuse -> span (identical on all ranks)."""
         self._sync()
         n = bs * num
-        rank, ws = parallel.world(self.process_group)
+        rank, ws = self._clip_world()
         lo, hi = parallel.shard_range(n, rank, ws)
         n_local = hi - lo
         out: Dict[str, object] = {"z": {}, "cls": {}, "sim": {}, "logit": {}, "full": {}}
@@ -321,12 +331,12 @@ class XInstructBLIP(nn.Module):
             with torch.cuda.stream(side):
                 enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
                 res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True)
-                z = parallel.all_gather_rows(res["query"], n, self.process_group)
-                cls = parallel.all_gather_rows(res["cls"], n, self.process_group)
+                z = self._gather(res["query"], n)
+                cls = self._gather(res["cls"], n)
                 sim, logit = scorer.cosine_scores(z, cls)
                 out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
                 if want_full:
-                    out["full"][m] = parallel.all_gather_rows(res["full"], n, self.process_group)
+                    out["full"][m] = self._gather(res["full"], n)
                 if want_llm:  # reference :303-306
                     y = qf.llm_proj(z)
                     out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
@@ -357,7 +367,7 @@ class XInstructBLIP(nn.Module):
         prompt = samples["text_input"]
         text = self.tokenizer(prompt, padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
         ids, tmask = text.input_ids.to(self._device), text.attention_mask.to(self._device)
-        rank, ws = parallel.world(self.process_group)
+        rank, ws = self._clip_world()
         embeds, index = {}, {}
         bs = num = None
         for m in self.modalities:
@@ -389,6 +399,19 @@ class XInstructBLIP(nn.Module):
             ts = [list(range(out["num"]))] * out["bs"]
         ts = [t.tolist() if torch.is_tensor(t) else list(t) for t in ts]
         return [o.strip() for o in scorer.spans_to_text(spans, ts)]
+
+    @torch.no_grad()
+    def generate_with_scores(self, samples):
+        """``generate`` plus the fused per-position logits ``[B][T]`` the spans were cut from (the
+        ``pred_saliency_scores`` of the highlight metrics, ``eval/mr_eval.py:291-325``)."""
+        out = self.encode_fuse(samples)
+        spans = out["spans"].cpu().tolist()
+        ts = samples.get("timestamps")
+        if ts is None:
+            ts = [list(range(out["num"]))] * out["bs"]
+        ts = [t.tolist() if torch.is_tensor(t) else list(t) for t in ts]
+        scores = out["fused"].view(out["bs"], out["num"]).float().cpu().tolist()
+        return [o.strip() for o in scorer.spans_to_text(spans, ts)], scores
 
     def _targets(self, samples, bs, num):
         """Clip-membership targets of the spans in ``samples["text_output"]`` (``"[[s, e]]"`` seconds)."""
