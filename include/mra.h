@@ -163,6 +163,13 @@ int mra_span_from_logits(const float* logits, int32_t videos, int32_t clips, flo
  *                                 Gradients flow to every Q-Former parameter incl. query_tokens and the
  *                                 embeddings; not to enc / ln.* / llm_proj.* (encoder side frozen). */
 size_t mra_qformer_grad_bytes(mra_qformer* h);
+/* Optimizer-side fast path: refreshes EVERY bert.* parameter in one launch from a flat f32 master buffer
+ * laid out exactly like the gradient buffer (parameter `name` at mra_qformer_grad_offset(name)), converting
+ * matrices to the operand dtype on the way.  An optimizer that keeps its master weights in that layout
+ * (mraudio_amd.qformer re-points every nn.Parameter at its slice) pays one ~0.3 ms kernel per step instead of
+ * ~400 mra_qformer_load calls.  query_tokens / ln.* / llm_proj.* still go through mra_qformer_load.
+ * No counterpart in the reference (DDP + torch.optim over autograd parameters, utils/trainer.py:60-69). */
+int32_t mra_qformer_load_flat(mra_qformer* h, const float* master, size_t master_bytes, void* stream);
 int mra_qformer_grad_offset(mra_qformer* h, const char* name, size_t* offset_bytes, int64_t* numel);
 int mra_qformer_enable_training(mra_qformer* h, void* stream);
 size_t mra_qformer_train_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv);

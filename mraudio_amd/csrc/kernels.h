@@ -151,6 +151,11 @@ int launch_embed_ln(const long long* ids, int items, int L, int Q, int H, int vo
                     const float* pos, const float* gain, const float* bias, float eps, float* h32, void* h16,
                     float* pre32 /* optional: rows before the LayerNorm (training) */, int op_dtype, hipStream_t stream);
 // dst(op dtype)[rows][cols] at row offset <- src (0 = f32, 1 = f16, 2 = bf16)
+// One launch that refreshes many parameters from a flat f32 master buffer: segment s copies / converts
+// n (<= FLAT_SEG) elements from master + src_off to dst in the stored dtype (0 f32, 1 f16, 2 bf16).
+struct FlatSeg { unsigned long long src_off; void* dst; int n; int dtype; };
+constexpr int FLAT_SEG = 16384;
+int launch_convert_flat(const float* master, const FlatSeg* segs, int nseg, hipStream_t stream);
 int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype /*0 f32,1 f16,2 bf16*/, long long n,
                    hipStream_t stream);
 int launch_copy_rows_f32(const float* src, RowView sv, float* dst, RowView dv, int rows, int H, hipStream_t stream);

@@ -235,6 +235,23 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
     return fail(MRA_ENOMEM, std::string("hipMalloc of parameter arena: ") + hipGetErrorString(e));
   }
   layout_params(h, h->arena);
+  // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
+  std::vector<FlatSeg> segs;
+  for (auto& kv : h->params) {
+    if (kv.first.rfind("bert.", 0) != 0) continue;
+    const Param& pr = kv.second;
+    const size_t esz = pr.dtype == MRA_F32 ? 4 : 2;
+    for (long long o = 0; o < pr.numel; o += FLAT_SEG)
+      segs.push_back(FlatSeg{(unsigned long long)(pr.goff / 4 + o), (char*)pr.ptr + o * esz,
+                             (int)std::min<long long>(FLAT_SEG, pr.numel - o), pr.dtype});
+  }
+  h->n_flat_segs = (int)segs.size();
+  e = hipMalloc((void**)&h->flat_segs, segs.size() * sizeof(FlatSeg));
+  if (e == hipSuccess) e = hipMemcpy(h->flat_segs, segs.data(), segs.size() * sizeof(FlatSeg), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    mra_qformer_destroy(h);
+    return fail(MRA_ENOMEM, std::string("segment table: ") + hipGetErrorString(e));
+  }
   *out = h;
   return MRA_OK;
 }
@@ -243,6 +260,7 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
   if (h->arena_t) (void)hipFree(h->arena_t);
+  if (h->flat_segs) (void)hipFree(h->flat_segs);
   delete h;
 }
 
@@ -262,6 +280,18 @@ int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t 
   const int rc = launch_convert(src, dtype, it->second.ptr, it->second.dtype, numel, as_stream(stream));
   if (rc) return chk(rc, "launch_convert");
   it->second.loaded = true;
+  h->transposes_stale = true;
+  return MRA_OK;
+}
+
+int mra_qformer_load_flat(mra_qformer* h, const float* master, size_t master_bytes, void* stream) {
+  if (!h || !master) return fail(MRA_EINVAL, "null argument");
+  if (master_bytes < h->grad_bytes) return fail(MRA_EINVAL, "master buffer smaller than mra_qformer_grad_bytes()");
+  if ((size_t)master & 15) return fail(MRA_EINVAL, "master buffer must be 16-byte aligned");
+  const int rc = launch_convert_flat(master, h->flat_segs, h->n_flat_segs, as_stream(stream));
+  if (rc) return chk(rc, "launch_convert_flat");
+  for (auto& kv : h->params)
+    if (kv.first.rfind("bert.", 0) == 0) kv.second.loaded = true;
   h->transposes_stale = true;
   return MRA_OK;
 }

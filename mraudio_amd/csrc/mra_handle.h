@@ -90,6 +90,8 @@ struct mra_qformer {
   char* arena_t = nullptr;      // transposed weight copies
   bool transposes_stale = true;
   size_t grad_bytes = 0;
+  mra::FlatSeg* flat_segs = nullptr;  // device table behind mra_qformer_load_flat (bert.* parameters)
+  int n_flat_segs = 0;
   int op() const { return cfg.op_dtype == MRA_BF16 ? mra::OP_BF16 : mra::OP_F16; }
 };
 

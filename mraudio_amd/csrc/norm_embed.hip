@@ -223,6 +223,17 @@ __global__ void __launch_bounds__(256) convert_kernel(const TI* src, TO* dst, lo
   }
 }
 
+__global__ void __launch_bounds__(256) convert_flat_kernel(const float* master, const FlatSeg* segs) {
+  const FlatSeg sg = segs[blockIdx.x];
+  const float* src = master + sg.src_off;
+  for (int i = threadIdx.x * 4; i < sg.n; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+    if (sg.dtype == 0) *reinterpret_cast<f32x4*>((float*)sg.dst + i) = v;
+    else if (sg.dtype == 1) store4<f16>((f16*)sg.dst + i, v);
+    else store4<bf16>((bf16*)sg.dst + i, v);
+  }
+}
+
 __global__ void __launch_bounds__(256) copy_rows_kernel(const float* src, RowView sv, float* dst, RowView dv, int rows,
                                                         int H) {
   const int lane = threadIdx.x & 63;
@@ -336,6 +347,12 @@ int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, lon
     case 2: return convert_i<bf16>(src, dst, dst_dtype, n, stream);
   }
   return -2;
+}
+
+int launch_convert_flat(const float* master, const FlatSeg* segs, int nseg, hipStream_t stream) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(convert_flat_kernel, dim3(nseg), dim3(256), 0, stream, master, segs);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int launch_copy_rows_f32(const float* src, RowView sv, float* dst, RowView dv, int rows, int H, hipStream_t stream) {

@@ -433,7 +433,12 @@ class XInstructBLIP(nn.Module):
             qf.enable_training()
             qt = getattr(self, f"{m}_query_tokens")
             qt.requires_grad_(True)
-            qf._extra_grad_binder = (lambda qf=qf, qt=qt: setattr(qt, "grad", qf.grad_of("query_tokens").view_as(qt)))
+
+            def binder(qf=qf, qt=qt):
+                qt.grad = qf.grad_of("query_tokens").view_as(qt)
+                self._extras_dirty = True      # fused optimizers do not bump version counters (see QFormer._run_backward)
+
+            qf._extra_grad_binder = binder
 
     def forward(self, samples):
         """Reference ``:399-606`` returns the LLM's cross-entropy.  Without an LLM on this path the

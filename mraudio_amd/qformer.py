@@ -237,8 +237,15 @@ class QFormer(nn.Module):
             self._dirty = True
         if not self._dirty:
             return
-        for k, v in self.bert.state_dict(prefix="bert.").items():
-            self.push(k, v)
+        if getattr(self, "_master_flat", None) is not None:
+            # training: the parameters are views of one flat f32 master buffer -> one launch refreshes all
+            self._bind_master()
+            with torch.cuda.device(self._device):
+                check(lib().mra_qformer_load_flat(self._handle, ptr(self._master_flat), self._master_flat.numel() * 4, current_stream()),
+                      "mra_qformer_load_flat")
+        else:
+            for k, v in self.bert.state_dict(prefix="bert.").items():
+                self.push(k, v)
         self._dirty = False
 
     def missing(self) -> List[str]:
@@ -395,8 +402,32 @@ def _qformer_enable_training(self: "QFormer") -> None:
         self._grad_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
         self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
         self._train_ws = None
-        for p in self.bert.parameters():
+        self._slices = {}
+        for k, p in self.bert.state_dict(prefix="bert.", keep_vars=True).items():
+            off, numel = C.c_size_t(), C.c_int64()
+            check(lib().mra_qformer_grad_offset(self._handle, k.encode(), C.byref(off), C.byref(numel)), f"grad_offset({k})")
+            self._slices[k] = (off.value // 4, int(numel.value), p)
             p.requires_grad_(True)
+        # master weights: one flat f32 buffer in the gradient buffer's layout; every parameter becomes a view of
+        # it, so any optimizer updates it in place and mra_qformer_load_flat refreshes the device copies at once
+        self._master_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
+        self._bind_master()
+
+
+def _qformer_bind_master(self: "QFormer") -> None:
+    """(Re-)point every ``bert.*`` parameter at its slice of the master buffer.  ``module.to()`` /
+    ``load_state_dict(assign=True)`` replace parameter storage; the current values are carried over."""
+    base = self._master_flat.data_ptr()
+    first = next(iter(self._slices.values()))
+    if first[2].data_ptr() == base + first[0] * 4 and getattr(self, "_master_bound", False):
+        return
+    with torch.no_grad():
+        for off, numel, p in self._slices.values():
+            view = self._master_flat[off: off + numel].view(p.shape)
+            if p.data_ptr() != view.data_ptr():
+                view.copy_(p.data)
+                p.data = view
+    self._master_bound = True
 
 
 def _qformer_grad_of(self: "QFormer", name: str) -> torch.Tensor:
@@ -407,9 +438,11 @@ def _qformer_grad_of(self: "QFormer", name: str) -> torch.Tensor:
 
 
 def _qformer_bind_grads(self: "QFormer") -> None:
-    for k, p in self.bert.state_dict(prefix="bert.", keep_vars=True).items():
-        if p.grad is None or p.grad.data_ptr() != self.grad_of(k).data_ptr():
-            p.grad = self.grad_of(k).view_as(p)
+    probe = self.bert.embeddings.LayerNorm.weight
+    if probe.grad is not None and probe.grad.data_ptr() == self.grad_of("bert.embeddings.LayerNorm.weight").data_ptr():
+        return                                   # still bound from the previous backward
+    for off, numel, p in self._slices.values():
+        p.grad = self._grad_flat[off: off + numel].view(p.shape)
 
 
 def _qformer_forward_train(self: "QFormer", input_ids, attention_mask, enc, want_cls: bool = True):
@@ -439,10 +472,14 @@ def _qformer_run_backward(self: "QFormer", input_ids, attention_mask, enc, N, L,
     binder = getattr(self, "_extra_grad_binder", None)
     if binder is not None:
         binder()
+    # A backward is followed by an optimizer step sooner or later, and fused optimizers (torch._fused_adam_)
+    # update parameters WITHOUT bumping their version counters: presume the device copies stale from here on.
+    self._dirty = True
 
 
 QFormer.enable_training = _qformer_enable_training
 QFormer.grad_of = _qformer_grad_of
 QFormer._bind_grads = _qformer_bind_grads
+QFormer._bind_master = _qformer_bind_master
 QFormer.forward_train = _qformer_forward_train
 QFormer._run_backward = _qformer_run_backward
