@@ -258,6 +258,244 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention backward on the matrix cores (v_mfma_f32_32x32x16, fp32 accumulate)
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (item, head), 4 waves.  A wave owns one 32-token K/V block per round (4 blocks in
+// flight), keeps dK / dV of that block in registers and walks the 32-row query blocks; the Q and dO tiles
+// of the current query block are shared.  All tiles are [32 rows][64 d] 16-bit, 128-byte rows, staged by
+// LDS-DMA with the 16-byte-chunk swizzle c ^ (((row >> 1) & 1) << 2) on the source address (the V tile
+// of attention.hip / the operand tiles of gemm_tn.hip).  Two kinds of fragment come out of a tile:
+//   direct  F_X[ks]   lane (row l & 31) reads 16 bytes = d 16 ks + 8 (l >> 5) .. + 7     (contraction over d)
+//   tr      T_X[ct,s] ds_read_b64_tr_b16: lane (column 32 ct + (l & 31)) gets rows 16 s + {4h..4h+3, 8+4h..8+4h+3}
+//                     -- exactly the row order of an MFMA accumulator's registers, so P / dS go from the
+//                     accumulator to the next MFMA's A operand without touching LDS   (contraction over rows)
+// Both orientations of the score tile are computed (S = Q K^T with the token on the lane axis feeds dV and
+// dK, S^T = K Q^T with the query on the lane axis feeds dQ): 8 extra MFMAs per tile pair instead of a
+// transpose through LDS.  dQ partials of the four waves meet in an fp32 LDS tile through ds_add_f32.
+namespace bwd {
+constexpr int TILE = 32 * 128;  // bytes of one [32][64] 16-bit tile
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type direct_frag(const char* tile, int lane, int ks) {
+  const int r = lane & 31, c = 2 * ks + (lane >> 5);
+  return lds_read8<T>(tile + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4));
+}
+
+// both k-steps (rows 0-15, 16-31) of column tile ct, as two 8-element operands
+template <typename T>
+__device__ __forceinline__ void tr_frags(unsigned tile, unsigned lane_off_ct, typename Vec8<T>::type& s0, typename Vec8<T>::type& s1) {
+  i16x4 a0, a1, a2, a3;
+  const unsigned addr = tile + lane_off_ct;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4\n\t"
+      "ds_read_b64_tr_b16 %1, %4 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:2048\n\t"
+      "ds_read_b64_tr_b16 %3, %4 offset:3072\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+      : "v"(addr)
+      : "memory");
+  i16x8 v0, v1;
+  v0[0] = a0[0]; v0[1] = a0[1]; v0[2] = a0[2]; v0[3] = a0[3]; v0[4] = a1[0]; v0[5] = a1[1]; v0[6] = a1[2]; v0[7] = a1[3];
+  v1[0] = a2[0]; v1[1] = a2[1]; v1[2] = a2[2]; v1[3] = a2[3]; v1[4] = a3[0]; v1[5] = a3[1]; v1[6] = a3[2]; v1[7] = a3[3];
+  s0 = __builtin_bit_cast(typename Vec8<T>::type, v0);
+  s1 = __builtin_bit_cast(typename Vec8<T>::type, v1);
+}
+}  // namespace bwd
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const AttnBwdArgs a) {
+  using V8 = typename Vec8<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.x % a.heads, item = blockIdx.x / a.heads;
+  const int nqb = (a.q_rows + 31) / 32, nkb = (a.kv_len + 31) / 32;
+  const int h = lane >> 5, ln = lane & 31;
+
+  char* Qs = smem_raw;                                   // shared Q tile
+  char* dOs = Qs + bwd::TILE;                            // shared dO tile
+  char* KVs = dOs + bwd::TILE;                           // per wave: K tile, V tile
+  float* dQs = reinterpret_cast<float*>(KVs + 4 * 2 * bwd::TILE);   // [nqb*32][64]
+  float* lse_s = dQs + nqb * 32 * 64;                    // [nqb*32]
+  float* delta_s = lse_s + nqb * 32;                     // [nqb*32]
+  float* mterm_s = delta_s + nqb * 32;                   // [4][32]
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+  const unsigned q_tile = lds0, do_tile = lds0 + bwd::TILE;
+  const unsigned k_tile = lds0 + 2 * bwd::TILE + wave * 2 * bwd::TILE, v_tile = k_tile + bwd::TILE;
+  const char* Kw = KVs + wave * 2 * bwd::TILE;   // this wave's K tile, V tile behind it
+  const char* Vw = Kw + bwd::TILE;
+
+  const T* Qg = (const T*)a.Q + (long long)item * a.q_item_stride + head * 64;
+  const T* dOg = (const T*)a.dO + (long long)item * a.o_item_stride + head * 64;
+  const T* Og = (const T*)a.O + (long long)item * a.o_item_stride + head * 64;
+  const T* Kg = (const T*)a.K + (long long)item * a.k_item_stride + (long long)head * a.k_head_stride;
+  const T* Vg = (const T*)a.V + (long long)item * a.v_item_stride + (long long)head * a.v_head_stride;
+  T* dQg = (T*)a.dQ + (long long)item * a.dq_item_stride + head * 64;
+  T* dKg = (T*)a.dK + (long long)item * a.dk_item_stride + (long long)head * a.dk_head_stride;
+  T* dVg = (T*)a.dV + (long long)item * a.dv_item_stride + (long long)head * a.dv_head_stride;
+
+  for (int i = tid; i < nqb * 32 * 64; i += 256) dQs[i] = 0.f;
+  // delta[q] = sum_d dO[q][d] O[q][d]: 8 lanes per row, 16 bytes each
+  for (int base = 0; base < nqb * 32; base += 32) {
+    const int q = base + (tid >> 3), c = tid & 7;
+    float sacc = 0.f;
+    if (q < a.q_rows) {
+      const V8 o = *reinterpret_cast<const V8*>(Og + (long long)q * a.o_ld + c * 8);
+      const V8 g = *reinterpret_cast<const V8*>(dOg + (long long)q * a.o_ld + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sacc += (float)o[j] * (float)g[j];
+    }
+    sacc += __shfl_xor(sacc, 1);
+    sacc += __shfl_xor(sacc, 2);
+    sacc += __shfl_xor(sacc, 4);
+    if (c == 0) {
+      delta_s[q] = sacc;
+      lse_s[q] = q < a.q_rows ? a.lse[((long long)item * a.heads + head) * a.q_rows + q] : 0.f;
+    }
+  }
+  // transposed-read lane offsets for the two 32-column halves of a tile (gemm_tn.hip)
+  unsigned tr_off[2];
+  {
+    const int g = lane >> 4, i = lane & 15, q4 = i >> 2, p = i & 3;
+    const int row = 4 * h + q4;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = 4 * ct + 2 * (g & 1) + (p >> 1);
+      tr_off[ct] = row * 128 + ((c ^ (((q4 >> 1) & 1) << 2)) << 4) + (p & 1) * 8;
+    }
+  }
+  const float sl2 = a.scale * LOG2E_B;
+  const int nrounds = (nkb + 3) / 4;
+  for (int rnd = 0; rnd < nrounds; ++rnd) {
+    const int kb = rnd * 4 + wave;
+    const bool active = kb < nkb;   // wave-uniform
+    const int t0 = kb * 32;
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), sc = lane & 7;
+        const int tok = min(t0 + row, a.kv_len - 1);
+        const int src = (sc ^ (((row >> 1) & 1) << 2)) * 8;
+        glds16(Kg + (long long)tok * a.k_ld + src, (char*)Kw + i * 1024);
+        glds16(Vg + (long long)tok * a.v_ld + src, (char*)Vw + i * 1024);
+      }
+      if (lane < 32) {
+        const int tok = t0 + lane;
+        float m = 0.f;
+        if (a.mask && tok < a.kv_len) m = (1.0f - (float)a.mask[(long long)item * a.mask_ld + tok]) * (-10000.0f * LOG2E_B);
+        mterm_s[wave * 32 + lane] = m;
+      }
+    }
+    f32x16 accK[2], accV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accK[0][i] = 0.f; accK[1][i] = 0.f; accV[0][i] = 0.f; accV[1][i] = 0.f; }
+    for (int qb = 0; qb < nqb; ++qb) {
+      __syncthreads();   // everyone is done with the previous Q / dO tiles
+      {
+        const int row = tid >> 3, sc = tid & 7;
+        const int q = min(qb * 32 + row, a.q_rows - 1);
+        const int src = (sc ^ (((row >> 1) & 1) << 2)) * 8;
+        glds16(Qg + (long long)q * a.q_ld + src, Qs + wave * 1024);
+        glds16(dOg + (long long)q * a.o_ld + src, dOs + wave * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (!active) continue;
+      const int q0 = qb * 32;
+      // ---- token on the lane axis: S[q][t], dP[q][t] -> P, dS -> dV, dK ------------------------------
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32<T>(bwd::direct_frag<T>(Qs, lane, ks), bwd::direct_frag<T>(Kw, lane, ks), s);
+        dp = mfma32<T>(bwd::direct_frag<T>(dOs, lane, ks), bwd::direct_frag<T>(Vw, lane, ks), dp);
+      }
+      {
+        const float mt = mterm_s[wave * 32 + ln];
+        const bool tok_ok = t0 + ln < a.kv_len;
+        V8 p8[2], ds8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float p = 0.f;
+          if (tok_ok && q < a.q_rows) p = __builtin_amdgcn_exp2f(s[r] * sl2 + mt - lse_s[q]);
+          const float d = p * (dp[r] - delta_s[q]) * a.scale;
+          p8[r >> 3][r & 7] = from_f32<T>(p);
+          ds8[r >> 3][r & 7] = from_f32<T>(d);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          V8 b0, b1;
+          bwd::tr_frags<T>(do_tile, tr_off[ct], b0, b1);
+          accV[ct] = mfma32<T>(p8[0], b0, accV[ct]);
+          accV[ct] = mfma32<T>(p8[1], b1, accV[ct]);
+          bwd::tr_frags<T>(q_tile, tr_off[ct], b0, b1);
+          accK[ct] = mfma32<T>(ds8[0], b0, accK[ct]);
+          accK[ct] = mfma32<T>(ds8[1], b1, accK[ct]);
+        }
+      }
+      // ---- query on the lane axis: S^T[t][q], dP^T[t][q] -> dS^T -> dQ ---------------------------------
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32<T>(bwd::direct_frag<T>(Kw, lane, ks), bwd::direct_frag<T>(Qs, lane, ks), s);
+        dp = mfma32<T>(bwd::direct_frag<T>(Vw, lane, ks), bwd::direct_frag<T>(dOs, lane, ks), dp);
+      }
+      {
+        const int q = q0 + ln;
+        const bool q_ok = q < a.q_rows;
+        const float lq = lse_s[q], dq = delta_s[q];
+        V8 ds8[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float p = 0.f;
+          if (q_ok && t0 + tl < a.kv_len) p = __builtin_amdgcn_exp2f(s[r] * sl2 + mterm_s[wave * 32 + tl] - lq);
+          ds8[r >> 3][r & 7] = from_f32<T>(p * (dp[r] - dq) * a.scale);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          V8 b0, b1;
+          bwd::tr_frags<T>(k_tile, tr_off[ct], b0, b1);
+          f32x16 accQ;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) accQ[i] = 0.f;
+          accQ = mfma32<T>(ds8[0], b0, accQ);
+          accQ = mfma32<T>(ds8[1], b1, accQ);
+          // rows q (registers), column d = 32 ct + ln
+          float* dst = dQs + (size_t)q0 * 64 + 32 * ct + ln;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(dst + ((r & 3) + 8 * (r >> 2) + 4 * h) * 64, accQ[r]);
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tok = t0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (tok < a.kv_len) {
+            dKg[(long long)tok * a.dk_ld + 32 * ct + ln] = from_f32<T>(accK[ct][r]);
+            dVg[(long long)tok * a.dv_ld + 32 * ct + ln] = from_f32<T>(accV[ct][r]);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.q_rows * 8; i += 256) {
+    const int q = i >> 3, c = (i & 7) * 8;
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(dQs[q * 64 + c + j]);
+    *reinterpret_cast<V8*>(dQg + (long long)q * a.dq_ld + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // embeddings backward: d_emb [items][Q + L][H] f32
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* demb, const long long* ids, int items, int L, int Q, int H,
@@ -331,16 +569,31 @@ int launch_gelu(const void* u, const void* df, void* out, long long n, int backw
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-size_t attn_bwd_lds_bytes(int q_rows) {
+size_t attn_bwd_lds_bytes(int q_rows) {   // the fp32 VALU kernel (kept for A/B: attn_bwd_force_valu)
   const int nqb = (q_rows + QB - 1) / QB;
   return sizeof(float) * ((size_t)nqb * QB * PADW + 2 * QB * PADW + 4 * KB * PADW + 2 * QB * (KB + 1) + 2 * nqb * QB);
 }
 
+static int g_attn_bwd_valu = 0;
+void attn_bwd_force_valu(int on) { g_attn_bwd_valu = on; }
+
 int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream) {
   if (a.items <= 0 || a.heads <= 0 || a.q_rows <= 0 || a.kv_len <= 0 || !a.lse) return -1;
-  const size_t lds = attn_bwd_lds_bytes(a.q_rows);
+  if (g_attn_bwd_valu) {
+    const size_t lds = attn_bwd_lds_bytes(a.q_rows);
+    if (lds > 160 * 1024) return -1;
+    void (*kfn)(const AttnBwdArgs) = op_dtype == OP_F16 ? attn_bwd_kernel<f16> : attn_bwd_kernel<bf16>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+    hipLaunchKernelGGL(kfn, dim3(a.items * a.heads), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+  }
+  // 16-byte operand rows: every leading dimension / stride a multiple of 8 elements
+  if ((a.q_ld | a.o_ld | a.dq_ld | a.k_ld | a.v_ld) & 7) return -1;
+  if ((a.q_item_stride | a.o_item_stride | a.dq_item_stride | a.k_item_stride | a.k_head_stride | a.v_item_stride | a.v_head_stride) & 7) return -1;
+  const int nqb = (a.q_rows + 31) / 32;
+  const size_t lds = 10 * (size_t)bwd::TILE + sizeof(float) * ((size_t)nqb * 32 * 64 + 2 * nqb * 32 + 4 * 32);
   if (lds > 160 * 1024) return -1;
-  void (*kfn)(const AttnBwdArgs) = op_dtype == OP_F16 ? attn_bwd_kernel<f16> : attn_bwd_kernel<bf16>;
+  void (*kfn)(const AttnBwdArgs) = op_dtype == OP_F16 ? attn_bwd_mfma_kernel<f16> : attn_bwd_mfma_kernel<bf16>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
   hipLaunchKernelGGL(kfn, dim3(a.items * a.heads), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -4;

@@ -107,6 +107,7 @@ struct AttnBwdArgs {
   float scale;
 };
 int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream);
+void attn_bwd_force_valu(int on);   // A/B switch: the first (fp32 VALU) kernel instead of the MFMA one
 int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, int Q, int H, int vocab, float* dquery, float* dpos,
                      float* dword, hipStream_t stream);
 int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, hipStream_t stream);

@@ -621,8 +621,8 @@ static void test_gelu_transpose_embed() {
 }
 
 // attention backward + the forward's LSE: self (packed QKV, mask) or cross (head-major)
-static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool self) {
-  const int op = OP_F16, H = heads * 64, ldqkv = 3 * H;
+static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool self, bool valu = false, int op_ = OP_F16) {
+  const int op = op_, H = heads * 64, ldqkv = 3 * H;
   std::vector<uint16_t> Q, K, V, dO((size_t)items * q_rows * H);
   std::vector<long long> mask;
   if (self) {
@@ -669,7 +669,9 @@ static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool sel
   b.k_item_stride = f.k_item_stride; b.k_head_stride = f.k_head_stride; b.v_item_stride = f.v_item_stride; b.v_head_stride = f.v_head_stride;
   b.k_ld = f.k_ld; b.v_ld = f.v_ld; b.mask = f.mask; b.mask_ld = f.mask_ld; b.lse = dlse.p;
   b.items = items; b.heads = heads; b.q_rows = q_rows; b.kv_len = kv_len; b.scale = 0.125f;
+  attn_bwd_force_valu(valu ? 1 : 0);
   rc |= launch_attn_bwd(b, op, 0);
+  attn_bwd_force_valu(0);
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> rQ = gQ.get(), rK = gK.get(), rV = gV.get();
   std::vector<float> lse = dlse.get();
@@ -721,11 +723,13 @@ static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool sel
       }
     }
   char name[96];
-  snprintf(name, sizeof(name), "attn %s items%d heads%d q%d kv%d", self ? "self" : "cross", items, heads, q_rows, kv_len);
-  report(std::string(name) + " forward LSE", wl, 2e-3);
-  report(std::string(name) + " backward dQ", wq, 6e-3);
-  report(std::string(name) + " backward dK", wk, 6e-3);
-  report(std::string(name) + " backward dV", wv, 6e-3);
+  snprintf(name, sizeof(name), "attn %s %s%s items%d heads%d q%d kv%d", self ? "self" : "cross", op == OP_F16 ? "f16" : "bf16",
+           valu ? " valu" : " mfma", items, heads, q_rows, kv_len);
+  const double tol = op == OP_F16 ? 6e-3 : 4e-2;
+  report(std::string(name) + " forward LSE", wl, op == OP_F16 ? 2e-3 : 1e-2);
+  report(std::string(name) + " backward dQ", wq, tol);
+  report(std::string(name) + " backward dK", wk, tol);
+  report(std::string(name) + " backward dV", wv, tol);
 }
 
 int main(int argc, char** argv) {
@@ -745,6 +749,13 @@ int main(int argc, char** argv) {
   test_attn_bwd(3, 2, 45, 45, true);
   test_attn_bwd(2, 2, 160, 160, true);
   test_attn_bwd(3, 2, 32, 257, false);
+  test_attn_bwd(2, 3, 64, 64, true);
+  test_attn_bwd(2, 2, 33, 33, true);
+  test_attn_bwd(1, 12, 32, 1000, false);
+  test_attn_bwd(2, 2, 41, 41, true, false, OP_BF16);
+  test_attn_bwd(2, 2, 32, 100, false, false, OP_BF16);
+  test_attn_bwd(3, 2, 45, 45, true, true);      // the fp32 VALU kernel (A/B switch)
+  test_attn_bwd(3, 2, 32, 257, false, true);
   test_ln_rows(OP_F16);
   test_ln_rows(OP_BF16);
   test_modality_ln(0, 1408);
