@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
     return ap.parse_args()
 
@@ -98,6 +99,7 @@ def main():
     op_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
     # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
+    model.kv_first = not args.no_kv_first
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = {m: torch.randn(n_local, kv[m], ENC_WIDTH[m], generator=g, device=dev, dtype=torch.float16) for m in ("video", "audio")}
     ids = torch.randint(1000, 30000, (n_local, L), generator=g, device=dev)

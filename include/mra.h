@@ -128,6 +128,12 @@ int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, v
  * K/V-projection launch, on the launch stream.  (NULL, NULL) switches it off. */
 int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
 
+/* Scheduling hook: when `ev` (hipEvent_t as void*) is non-NULL every following mra_qformer_forward records it
+ * right after its K/V-projection launch, on the launch stream.  The host side makes the light modality's
+ * stream wait for the heavy modality's event, so the chip-filling GEMM runs alone and the two latency-bound
+ * layer chains overlap each other instead (mraudio_amd/models/xinstructblip.py: fuse_score).  NULL = off. */
+int mra_qformer_set_kv_done_event(mra_qformer* h, void* ev);
+
 /* ---- A5: LLM projection ---------------------------------------------------------------------------
  * replaces: {modality}_llm_proj(last_hidden_state[:, :32, :]) (models/xinstructblip.py:303).
  * z [rows, hidden] f32 -> out [rows, llm_hidden] of out_dtype (MRA_F32 or the operand dtype).

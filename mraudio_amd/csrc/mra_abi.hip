@@ -399,6 +399,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
     if (rc) return chk(rc, "kv projection gemm");
     if (h->kv_ev0 && h->kv_ev1) (void)hipEventRecord(h->kv_ev1, stream);
   }
+  if (h->kv_done) (void)hipEventRecord(h->kv_done, stream);   // also without cross layers: the waiter must not hang
 
   const bool want_text_last = out_full != nullptr;
   const bool want_cls_last = !out_full && out_cls != nullptr;
@@ -577,6 +578,12 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
   if ((ev_start == nullptr) != (ev_stop == nullptr)) return fail(MRA_EINVAL, "give both events or neither");
   h->kv_ev0 = reinterpret_cast<hipEvent_t>(ev_start);
   h->kv_ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
+  return MRA_OK;
+}
+
+int mra_qformer_set_kv_done_event(mra_qformer* h, void* ev) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  h->kv_done = reinterpret_cast<hipEvent_t>(ev);
   return MRA_OK;
 }
 

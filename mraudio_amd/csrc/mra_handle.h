@@ -85,6 +85,7 @@ struct mra_qformer {
   float* bkv = nullptr;
   void* wllm = nullptr;
   float* bllm = nullptr;
+  hipEvent_t kv_done = nullptr;                   // optional scheduling hook (mra_qformer_set_kv_done_event)
   hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
   // training
   char* arena_t = nullptr;      // transposed weight copies
