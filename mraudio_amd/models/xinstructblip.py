@@ -116,7 +116,8 @@ class XInstructBLIP(nn.Module):
                  audio_encoder: Optional[nn.Module] = None, tokenizer=None, seed: Optional[int] = 0,
                  perturb: bool = False, op_dtype: torch.dtype = torch.float16, device=None,
                  compat_repeat: bool = True, score_alpha: float = 0.5, fuse_weights: Optional[Sequence[float]] = None,
-                 process_group=None, qformer_overrides: Optional[dict] = None, overlap_modalities: bool = True):
+                 process_group=None, qformer_overrides: Optional[dict] = None, overlap_modalities: bool = True,
+                 llm_hidden_size: int = 4096):
         super().__init__()
         self.model_path, self.audio_path = model_path, audio_path
         self.modalities = list(modalities) if modalities is not None else ["audio", "video"]  # reference :71
@@ -138,7 +139,10 @@ class XInstructBLIP(nn.Module):
         self.tokenizer = tokenizer if tokenizer is not None else self.init_tokenizer(truncation_side="left")
         self.video_encoder = video_encoder
         self.audio_encoder = audio_encoder
-        self.llm_hidden_size = 4096
+        self.llm_hidden_size = llm_hidden_size   # Vicuna-7B: 4096 (reference :167)
+        self.llm_model = None                    # stock causal LM, attached by attach_llm (row N2)
+        self.llm_tokenizer = None
+        self.prompt_assembler = None
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
         # synthetic init draws modalities in sorted order so the tensors do not depend on list order
         for m in sorted(self.modalities):
@@ -435,6 +439,46 @@ class XInstructBLIP(nn.Module):
         ts = [t.tolist() if torch.is_tensor(t) else list(t) for t in ts]
         scores = out["fused"].view(out["bs"], out["num"]).float().cpu().tolist()
         return [o.strip() for o in scorer.spans_to_text(spans, ts)], scores
+
+    # ---- row N2: the reference's own decode, for callers that attach a stock LLM ----------------------------
+    def attach_llm(self, llm_model: nn.Module, llm_tokenizer, enumerate_inputs: bool = False, interleave_seconds: bool = True) -> None:
+        """Attach a stock causal LM (``LlamaForCausalLM`` in the reference, ``:146-172``) and its tokenizer.  The hot
+        path then feeds it exactly as the reference does (``models/llm_prompt.py``); the LM runs as ordinary
+        PyTorch-ROCm.  Kept outside ``state_dict`` (the reference checkpoints hold the LLM separately)."""
+        from .llm_prompt import PromptAssembler
+
+        object.__setattr__(self, "llm_model", llm_model)
+        self.llm_tokenizer = llm_tokenizer
+        emb = llm_model.get_input_embeddings()
+        if emb.weight.shape[1] != self.llm_hidden_size:
+            raise MraError(f"LLM hidden size {emb.weight.shape[1]} != llm_hidden_size {self.llm_hidden_size} of the projections")
+        self.prompt_assembler = PromptAssembler(llm_tokenizer, emb, modalities=self.modalities, num_query_token=self.num_query_token,
+                                                enumerate_inputs=enumerate_inputs, interleave_seconds=interleave_seconds,
+                                                max_txt_len=self.max_txt_len, max_output_txt_len=self.max_output_txt_len, device=self._device)
+
+    def _llm_inputs(self, samples):
+        if self.prompt_assembler is None:
+            raise MraError("no LLM attached: call attach_llm(llm_model, llm_tokenizer) first")
+        with torch.no_grad():
+            out = self.encode_fuse(samples, want_llm=True)
+        dt = self.llm_model.get_input_embeddings().weight.dtype
+        return {m: v.to(dt) for m, v in out["inputs_llm"].items()}, out["atts_llm"]
+
+    @torch.no_grad()
+    def generate_llm(self, samples, max_new_tokens: int = 64) -> List[str]:
+        """Reference ``generate`` end to end (``:221-397``): hot path -> prompt assembly -> ``llm_model.generate``."""
+        inputs_llm, atts_llm = self._llm_inputs(samples)
+        embeds, mask = self.prompt_assembler.assemble_generate(samples, inputs_llm, atts_llm)
+        outputs = self.llm_model.generate(inputs_embeds=embeds, attention_mask=mask, max_new_tokens=max_new_tokens)
+        outputs[outputs == 0] = 2                                      # :392
+        return [o.strip() for o in self.llm_tokenizer.batch_decode(outputs, skip_special_tokens=True)]
+
+    def forward_llm(self, samples):
+        """Reference ``forward`` end to end (``:399-606``): the LM's cross-entropy on the answer tokens.  The Q-Former
+        side is computed without grad (frozen, as in the reference); the loss trains whatever the LM leaves trainable."""
+        inputs_llm, atts_llm = self._llm_inputs(samples)
+        embeds, mask, targets = self.prompt_assembler.assemble_forward(samples, inputs_llm, atts_llm)
+        return {"loss": self.llm_model(inputs_embeds=embeds, attention_mask=mask, return_dict=True, labels=targets).loss}
 
     def _targets(self, samples, bs, num):
         """Clip-membership targets of the spans in ``samples["text_output"]`` (``"[[s, e]]"`` seconds)."""

@@ -66,3 +66,33 @@ def test_trainer_epoch_on_the_hip_path(tmp_path):
     assert [h["epoch"] for h in tr2.history] == [2]
     w = "video_Qformer.bert.encoder.layer.0.crossattention.self.key.weight"
     assert tr2.history[0]["loss_value"] < tr.history[0]["loss_value"]
+
+
+def test_llm_decode_path_with_a_stock_llama():
+    """Row N2 on the device: hot path -> llm_proj -> prompt assembly -> an unmodified HF Llama (tiny random
+    config, hidden 256 = the projections' output width here) -> strings / LM loss, as reference generate / forward."""
+    tf = pytest.importorskip("transformers")
+    from mraudio_amd.models.llm_prompt import SimpleLlmTokenizer
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tok = SimpleLlmTokenizer()
+    cfg = tf.LlamaConfig(vocab_size=len(tok), hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=4, max_position_embeddings=4096, pad_token_id=tok.pad_token_id, bos_token_id=2, eos_token_id=2)
+    llm = tf.LlamaForCausalLM(cfg).to(dev).half().eval()
+    model = XInstructBLIP(seed=0, device=dev, llm_hidden_size=256)
+    model.attach_llm(llm, tok)
+    ds = SyntheticMRDataset(2, T=6, seed=5, duration=12)
+    batch = collate_fn([ds[0], ds[1]])
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = model.generate_llm(batch, max_new_tokens=8)
+    assert isinstance(out, list) and len(out) == 2 and all(isinstance(o, str) for o in out)
+    # the assembled sequence: 6 positions x (cue + 32 + cue + 32 + seconds) + duration + prompt, all from the HIP path's projections
+    inputs_llm, atts_llm = model._llm_inputs(batch)
+    assert inputs_llm["video"].shape == (2, 6 * 32, 256) and inputs_llm["video"].dtype == torch.float16
+    ref = model.encode_fuse(batch, want_llm=True)["inputs_llm"]["audio"]
+    assert torch.equal(inputs_llm["audio"], ref.to(torch.float16))
+    loss = model.forward_llm(batch)["loss"]
+    assert torch.isfinite(loss)
+    assert "llm_model.lm_head.weight" not in model.state_dict()     # the LLM is not part of this model's checkpoint
