@@ -346,7 +346,10 @@ class XInstructBLIP(nn.Module):
             # finished: a chip-filling GEMM gains nothing from sharing CUs with a latency-bound layer chain (it
             # ran 20 % longer beside one), whereas two layer chains overlap each other almost for free.
             live.sort(key=lambda m: int(embeds[m].shape[-2]) * int(embeds[m].shape[-1]), reverse=True)
-            heavy_done = self._kv_done_event(live[0])
+            heavy = live[0]
+            kv_flops = 2.0 * n_local * embeds[heavy].shape[-2] * embeds[heavy].shape[-1] * 9216
+            if kv_flops >= 1e12:                  # ~1 ms of GEMM; below that the wait costs more than the contention
+                heavy_done = self._kv_done_event(heavy)
         for pos, m in enumerate(live):
             qf: QFormer = getattr(self, f"{m}_Qformer")
             idx = None if index is None else index.get(m)
