@@ -141,6 +141,11 @@ int launch_attention(const AttnArgs& a, int op_dtype, hipStream_t stream);
 // y = LN(x) over H (multiple of 256, <= 1024) with gain/bias; writes f32 and/or op-dtype copies.
 int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, float eps,
                    float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream);
+// as launch_ln_rows, but rows with (row % period) >= split use (gain2, bias2): the query and the text LayerNorm
+// of a Q-Former layer in one launch over all rows of the [items, 32 + L, H] stream
+int launch_ln_rows2(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2,
+                    const float* bias2, int period, int split, float eps, float* y32, RowView y32v, void* y16, RowView y16v,
+                    int op_dtype, hipStream_t stream);
 // Modality LayerNorm (A2) fused with the item gather (A3): out item i <- LN(in item index[i]).
 // x dtype: 0 = f32, 1 = f16, 2 = bf16.
 int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, int items, int tokens, int E,

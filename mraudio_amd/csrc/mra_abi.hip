@@ -530,7 +530,12 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "ffn down gemm");
     }
-    if (!last) {
+    if (!last && text_rows == N * L && L > 0) {
+      // query and text LayerNorm in one launch: the two row sets are the whole [N, S, H] stream
+      rc = launch_ln_rows2(w.pre32, all_rows, N * S, H, Lw.lnqg, Lw.lnqb, Lw.lntg, Lw.lntb, S, Q, c.ln_eps, w.hA32, all_rows,
+                           w.hA16, all_rows, op, stream);
+      if (rc) return chk(rc, "ffn ln");
+    } else if (!last) {
       rc = launch_ln_rows(w.pre32, q_view, N * Q, H, Lw.lnqg, Lw.lnqb, c.ln_eps, w.hA32, q_view, w.hA16, q_view, op, stream);
       if (rc) return chk(rc, "ffn query ln");
       if (text_rows > 0) {

@@ -32,10 +32,13 @@ __device__ __forceinline__ void store4(T* p, f32x4 v) {
 template <typename T, int NV>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const float* x, RowView xv, int rows, const float* gain,
                                                       const float* bias, float eps, float* y32, RowView y32v, T* y16,
-                                                      RowView y16v) {
+                                                      RowView y16v, const float* gain2, const float* bias2, int period,
+                                                      int split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  // two parameter sets in one launch: rows [split, period) of every item (the text rows) take the second one
+  if (gain2 && row % period >= split) { gain = gain2; bias = bias2; }
   constexpr int H = NV * 256;
   const float* xr = x + vrow(xv, row);
   f32x4 v[NV];
@@ -293,12 +296,18 @@ int convert_i(const void* src, void* dst, int dst_dtype, long long n, hipStream_
 
 int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, float eps,
                    float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream) {
+  return launch_ln_rows2(x, xv, rows, H, gain, bias, nullptr, nullptr, 1, 1, eps, y32, y32v, y16, y16v, op_dtype, stream);
+}
+
+int launch_ln_rows2(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2,
+                    const float* bias2, int period, int split, float eps, float* y32, RowView y32v, void* y16, RowView y16v,
+                    int op_dtype, hipStream_t stream) {
   if (rows <= 0) return 0;
   if (H % 256 || H > 1024 || H <= 0) return -1;
   const dim3 grid((rows + 3) / 4), block(256);
 #define MRA_LN_CASE(T, NV)                                                                                         \
   hipLaunchKernelGGL((ln_rows_kernel<T, NV>), grid, block, 0, stream, x, xv, rows, gain, bias, eps, y32, y32v, \
-                     (T*)y16, y16v)
+                     (T*)y16, y16v, gain2, bias2, period, split)
   const int nv = H / 256;
   if (op_dtype == OP_F16) {
     if (nv == 1) MRA_LN_CASE(f16, 1); else if (nv == 2) MRA_LN_CASE(f16, 2); else if (nv == 3) MRA_LN_CASE(f16, 3); else MRA_LN_CASE(f16, 4);
