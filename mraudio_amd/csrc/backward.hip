@@ -530,6 +530,28 @@ __global__ void __launch_bounds__(256) transpose16_kernel(const T* src, T* dst, 
     if (bx + j < C && by + tx < R) dst[(long long)(bx + j) * R + by + tx] = tile[tx][j];
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) transpose16_batch_kernel(const TrJob* jobs, int njobs) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;                 // last job whose tile_begin <= b (workgroup-uniform binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const TrJob j = jobs[lo];
+  const int local = b - j.tile_begin;
+  const int bx = (local % j.tiles_x) * 32, by = (local / j.tiles_x) * 32;
+  const T* src = (const T*)j.src;
+  T* dst = (T*)j.dst;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    if (by + r < j.R && bx + tx < j.C) tile[r][tx] = src[(long long)(by + r) * j.C + bx + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bx + r < j.C && by + tx < j.R) dst[(long long)(bx + r) * j.R + by + tx] = tile[tx][r];
+}
+
 __global__ void __launch_bounds__(256) axpy_kernel(const float* x, float* y, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4), b = *reinterpret_cast<f32x4*>(y + i * 4);
@@ -603,6 +625,13 @@ int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, 
                      float* dword, hipStream_t stream) {
   if (items <= 0) return 0;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(Q + L), dim3(256), 0, stream, demb, ids, items, L, Q, H, vocab, dquery, dpos, dword);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_transpose16_batch(const TrJob* jobs_dev, int njobs, int total_tiles, int op_dtype, hipStream_t stream) {
+  if (njobs <= 0 || total_tiles <= 0) return 0;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(transpose16_batch_kernel<f16>, dim3(total_tiles), dim3(256), 0, stream, jobs_dev, njobs);
+  else hipLaunchKernelGGL(transpose16_batch_kernel<bf16>, dim3(total_tiles), dim3(256), 0, stream, jobs_dev, njobs);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -66,9 +66,13 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int ct_n = wave >> 1, ct_k = wave & 1;  // this wave's 32-column halves of the n and k blocks
 
-  f32x16 acc;
+  f32x16 acc, accb;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accb[i] = 0.f; }
+  const bool do_bias = a.db != nullptr && kb == 0 && ct_k == 0;   // wave-uniform
+  typename Vec8<T>::type ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = from_f32<T>(1.0f);
   const int nsteps = (M + BMT - 1) / BMT;
   const int per = (nsteps + (int)gridDim.z - 1) / (int)gridDim.z;
   const int s0 = blockIdx.z * per, s1 = min(nsteps, s0 + per);
@@ -119,6 +123,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
     }
     acc = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A0), __builtin_bit_cast(typename Vec8<T>::type, B0), acc);
     acc = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A1), __builtin_bit_cast(typename Vec8<T>::type, B1), acc);
+    if (do_bias) {   // every column of this product is the column sum of the dY tile
+      accb = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A0), ones, accb);
+      accb = mfma32<T>(__builtin_bit_cast(typename Vec8<T>::type, A1), ones, accb);
+    }
+  }
+  if (do_bias && (lane & 31) == 0) {
+    float* pb = a.db + nb * 64 + ct_n * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(pb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), accb[r]);
   }
   // D: column k = lane & 31, row n = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int kcol = kb * 64 + ct_k * 32 + (lane & 31);

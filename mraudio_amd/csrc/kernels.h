@@ -71,6 +71,8 @@ struct GemmTnArgs {
   int M, N, K;
   int ldw;
   int accumulate;  // 1: dW += ...
+  float* db;       // optional bias gradient db[n] += sum_m dY[m][n], always accumulated (the column-block-0 workgroups
+                   // multiply their dY fragments by a ones operand: two more MFMAs per step instead of a second launch)
 };
 int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream);
 // db[n] (+)= sum_m dY[m][n]
@@ -111,6 +113,9 @@ void attn_bwd_force_valu(int on);   // A/B switch: the first (fp32 VALU) kernel 
 int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, int Q, int H, int vocab, float* dquery, float* dpos,
                      float* dword, hipStream_t stream);
 int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, hipStream_t stream);
+// many transposes in one launch: job j owns the 32x32 tiles [tile_begin, next job's tile_begin) of its matrix
+struct TrJob { const void* src; void* dst; int R, C, tile_begin, tiles_x; };
+int launch_transpose16_batch(const TrJob* jobs_dev, int njobs, int total_tiles, int op_dtype, hipStream_t stream);
 int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream);  // y += x
 
 // ---- attention ------------------------------------------------------------------------------

@@ -261,6 +261,7 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->arena_t) (void)hipFree(h->arena_t);
   if (h->flat_segs) (void)hipFree(h->flat_segs);
+  if (h->tr_jobs) (void)hipFree(h->tr_jobs);
   delete h;
 }
 

@@ -90,6 +90,8 @@ struct mra_qformer {
   // training
   char* arena_t = nullptr;      // transposed weight copies
   bool transposes_stale = true;
+  mra::TrJob* tr_jobs = nullptr;   // device table of the batched transpose (built on first use)
+  int n_tr_jobs = 0, n_tr_tiles = 0;
   size_t grad_bytes = 0;
   mra::FlatSeg* flat_segs = nullptr;  // device table behind mra_qformer_load_flat (bert.* parameters)
   int n_flat_segs = 0;

@@ -113,20 +113,34 @@ size_t layout_transposes(mra_qformer* h, char* base) {
 int refresh_transposes(mra_qformer* h, hipStream_t stream) {
   const mra_cfg& c = h->cfg;
   const int H = c.hidden, I = c.inter, op = h->op();
-  for (int i = 0; i < c.layers; ++i) {
-    const LayerW& L = h->layers[i];
-    int rc = launch_transpose16(L.wqkv, L.wqkvT, 3 * H, H, op, stream);
-    rc |= launch_transpose16(L.wo, L.woT, H, H, op, stream);
-    if (L.cross_index >= 0) {
-      rc |= launch_transpose16(L.wcq, L.wcqT, H, H, op, stream);
-      rc |= launch_transpose16(L.wco, L.wcoT, H, H, op, stream);
+  if (!h->tr_jobs) {   // one launch for every weight: table of (matrix, first 32x32 tile)
+    std::vector<TrJob> jobs;
+    int tiles = 0;
+    auto add = [&](const void* src, void* dst, int R, int C) {
+      const int tx = (C + 31) / 32, ty = (R + 31) / 32;
+      jobs.push_back(TrJob{src, dst, R, C, tiles, tx});
+      tiles += tx * ty;
+    };
+    for (int i = 0; i < c.layers; ++i) {
+      const LayerW& L = h->layers[i];
+      add(L.wqkv, L.wqkvT, 3 * H, H);
+      add(L.wo, L.woT, H, H);
+      if (L.cross_index >= 0) {
+        add(L.wcq, L.wcqT, H, H);
+        add(L.wco, L.wcoT, H, H);
+      }
+      add(L.wiq, L.wiqT, I, H);
+      add(L.woq, L.woqT, H, I);
+      add(L.wit, L.witT, I, H);
+      add(L.wot, L.wotT, H, I);
     }
-    rc |= launch_transpose16(L.wiq, L.wiqT, I, H, op, stream);
-    rc |= launch_transpose16(L.woq, L.woqT, H, I, op, stream);
-    rc |= launch_transpose16(L.wit, L.witT, I, H, op, stream);
-    rc |= launch_transpose16(L.wot, L.wotT, H, I, op, stream);
-    if (rc) return rc;
+    if (hipMalloc((void**)&h->tr_jobs, jobs.size() * sizeof(TrJob)) != hipSuccess) return -3;
+    if (hipMemcpy(h->tr_jobs, jobs.data(), jobs.size() * sizeof(TrJob), hipMemcpyHostToDevice) != hipSuccess) return -4;
+    h->n_tr_jobs = (int)jobs.size();
+    h->n_tr_tiles = tiles;
   }
+  const int rc = launch_transpose16_batch(h->tr_jobs, h->n_tr_jobs, h->n_tr_tiles, op, stream);
+  if (rc) return rc;
   h->transposes_stale = false;
   return 0;
 }
@@ -149,10 +163,8 @@ struct Ctx {
     if (M <= 0) return 0;
     GemmTnArgs a{};
     a.dY = dY; a.X = X; a.dW = dW; a.yv = yv; a.xv = xv; a.y_block_stride = y_block_stride; a.x_block_stride = 64;
-    a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1;
-    int rc = launch_gemm_tn(a, op, stream);
-    if (!rc && db) rc = launch_colsum(dY, y_block_stride, yv, M, N, db, 1, op, stream);
-    return rc;
+    a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1; a.db = db;
+    return launch_gemm_tn(a, op, stream);
   }
 };
 

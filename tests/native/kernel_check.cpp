@@ -332,7 +332,7 @@ static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accum
   for (auto& v : W0) v = frand();
   for (auto& v : B0) v = frand();
   Dev<uint16_t> dY(Yd), dX(X);
-  Dev<float> dW(W0), dB(B0);
+  Dev<float> dW(W0), dB(B0), dB2(B0);
   GemmTnArgs a;
   memset(&a, 0, sizeof(a));
   a.dY = dY.p; a.X = dX.p; a.dW = dW.p;
@@ -340,15 +340,18 @@ static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accum
   a.xv = RowView{0, M, K}; a.x_block_stride = 64;
   if (headmajor) { a.yv = RowView{(long long)nblocks * kv * 64, kv, 64}; a.y_block_stride = (long long)kv * 64; }
   else { a.yv = RowView{0, M, N}; a.y_block_stride = 64; }
+  a.db = dB2.p;                                  // fused bias gradient (always accumulates)
   int rc = launch_gemm_tn(a, op, 0);
   rc |= launch_colsum(dY.p, a.y_block_stride, a.yv, M, N, dB.p, accumulate, op, 0);
   CK(hipDeviceSynchronize());
-  std::vector<float> W = dW.get(), B = dB.get();
-  double worst = rc ? 1e30 : 0, worstb = rc ? 1e30 : 0;
+  std::vector<float> W = dW.get(), B = dB.get(), B2 = dB2.get();
+  double worst = rc ? 1e30 : 0, worstb = rc ? 1e30 : 0, worstf = worstb;
   for (int n = 0; n < N && !rc; ++n) {
     double bs = accumulate ? B0[n] : 0;
     for (int m = 0; m < M; ++m) bs += Yf[(size_t)m * N + n];
     worstb = std::max(worstb, fabs(bs - B[n]) / (1 + fabs(bs)));
+    const double bf = bs + (accumulate ? 0 : B0[n]);
+    worstf = std::max(worstf, fabs(bf - B2[n]) / (1 + fabs(bf)));
     for (int k = 0; k < K; ++k) {
       double acc = accumulate ? W0[(size_t)n * K + k] : 0;
       for (int m = 0; m < M; ++m) acc += (double)Yf[(size_t)m * N + n] * Xf[(size_t)m * K + k];
@@ -359,6 +362,7 @@ static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accum
   snprintf(name, sizeof(name), "gemm_tn %s M%d N%d K%d %s%s", op == OP_F16 ? "f16" : "bf16", M, N, K, headmajor ? "head-major" : "row-major", accumulate ? " +=" : "");
   report(name, worst, 2e-5);
   report(std::string(name) + " colsum", worstb, 2e-5);
+  report(std::string(name) + " fused bias grad", worstf, 2e-5);
 }
 
 // ------------------------------------------------------------------------------------------------

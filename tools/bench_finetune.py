@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--per-tensor-adam", action="store_true", help="A/B: ~800 per-tensor parameters instead of the two flat ones")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -37,7 +38,10 @@ def main():
     samples = {"video_embeds": torch.randn(1, 20, 257, 1408, generator=g).to(dev), "audio_embeds": torch.randn(1, 20, 256, 768, generator=g).to(dev),
                "text_input": ["Query: a person opens the door and walks in.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
                "text_output": ["[[6, 12]]"], "timestamps": [list(range(0, 40, 2))], "duration": [40]}
-    params = [p for d in model.get_optimizer_params(0.05) for p in d["params"] if p.shape[0] != 30523]
+    if args.per_tensor_adam:
+        params = [p for d in model.get_optimizer_params(0.05) for p in d["params"] if p.shape[0] != 30523]
+    else:
+        params = model.flat_optimizer_params()       # one flat fp32 parameter per Q-Former
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)
     t = {"fwd": 0.0, "bwd": 0.0, "allreduce": 0.0, "adam": 0.0}
 
