@@ -350,6 +350,113 @@ class QFormer(nn.Module):
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
         return float(lib().mra_qformer_flops(self._handle, items, L, kv, int(with_last_text)))
 
+    # ---- training (BASELINE config 5): forward with an activation tape + HIP backward behind torch.autograd ----
+    def enable_training(self) -> None:
+        """Allocate the flat gradient buffer, bind every ``bert.*`` parameter's ``.grad`` to its slice and build
+        the transposed weight copies (call again after changing weights; ``forward_train`` does it lazily)."""
+        self.sync_weights()
+        with torch.cuda.device(self._device):
+            check(lib().mra_qformer_enable_training(self._handle, current_stream()), "mra_qformer_enable_training")
+        if getattr(self, "_grad_flat", None) is None:
+            n = int(lib().mra_qformer_grad_bytes(self._handle)) // 4
+            self._grad_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
+            self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
+            self._train_ws = None
+            self._slices = {}
+            for k, p in self.bert.state_dict(prefix="bert.", keep_vars=True).items():
+                self._slices[k] = (*self._slice_of(k), p)
+                p.requires_grad_(True)
+            # master weights: one flat f32 buffer in the gradient buffer's layout; every parameter becomes a view of
+            # it, so any optimizer updates it in place and mra_qformer_load_flat refreshes the device copies at once
+            self._master_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
+            self._bind_master()
+
+
+    def _bind_master(self) -> None:
+        """(Re-)point every ``bert.*`` parameter at its slice of the master buffer.  ``module.to()`` /
+        ``load_state_dict(assign=True)`` replace parameter storage; the current values are carried over."""
+        base = self._master_flat.data_ptr()
+        first = next(iter(self._slices.values()))
+        if first[2].data_ptr() == base + first[0] * 4 and getattr(self, "_master_bound", False):
+            return
+        with torch.no_grad():
+            for off, numel, p in self._slices.values():
+                view = self._master_flat[off: off + numel].view(p.shape)
+                if p.data_ptr() != view.data_ptr():
+                    view.copy_(p.data)
+                    p.data = view
+        self._master_bound = True
+
+
+    def grad_of(self, name: str) -> torch.Tensor:
+        """View of parameter ``name``'s gradient inside the flat buffer (ABI names, e.g. ``query_tokens``)."""
+        off, numel = C.c_size_t(), C.c_int64()
+        check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
+        return self._grad_flat[off.value // 4: off.value // 4 + numel.value]
+
+
+    def _bind_grads(self) -> None:
+        probe = self.bert.embeddings.LayerNorm.weight
+        if probe.grad is not None and probe.grad.data_ptr() == self.grad_of("bert.embeddings.LayerNorm.weight").data_ptr():
+            return                                   # still bound from the previous backward
+        for off, numel, p in self._slices.values():
+            p.grad = self._grad_flat[off: off + numel].view(p.shape)
+
+
+    def forward_train(self, input_ids, attention_mask, enc, want_cls: bool = True):
+        """Training forward: ``(out_query [N,32,H], out_cls [N,H])`` connected to autograd.  ``loss.backward()``
+        accumulates parameter gradients (``p.grad`` of every ``bert.*`` parameter, ``grad_of('query_tokens')``)."""
+        self.enable_training()
+        cfg = self.cfg
+        enc = enc.to(cfg.op_dtype).contiguous()
+        if input_ids is not None:
+            input_ids = input_ids.to(device=enc.device, dtype=torch.int64).contiguous()
+        if attention_mask is not None:
+            attention_mask = attention_mask.to(device=enc.device, dtype=torch.int64).contiguous()
+        q, c = _QFormerTrainFn.apply(self._anchor, self, input_ids, attention_mask, enc, want_cls)
+        return (q, c) if want_cls else (q, None)
+
+
+    def _slice_of(self, name: str):
+        off, numel = C.c_size_t(), C.c_int64()
+        check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
+        return off.value // 4, int(numel.value)
+
+
+    def flat_parameter(self) -> torch.nn.Parameter:
+        """ONE ``nn.Parameter`` over the whole master buffer with the whole gradient buffer as its ``.grad``: an
+        optimizer given this instead of the ~400 per-tensor parameters updates the Q-Former in one fused launch
+        (fused Adam over 186 M elements: 0.8 ms instead of 2.3 ms for the per-tensor lists).  The per-tensor
+        parameters stay valid views of the same memory (state_dict, checkpoints)."""
+        self.enable_training()
+        fp = getattr(self, "_flat_param", None)
+        if fp is None or fp.data_ptr() != self._master_flat.data_ptr():
+            fp = torch.nn.Parameter(self._master_flat, requires_grad=True)
+            object.__setattr__(self, "_flat_param", fp)      # not registered: it aliases the per-tensor parameters
+        fp.grad = self._grad_flat
+        return fp
+
+
+    def _run_backward(self, input_ids, attention_mask, enc, N, L, Kv, d_q, d_c) -> None:
+        # optimizer.zero_grad(set_to_none=True) drops the views: start from a clean buffer in that case
+        probe = self.bert.embeddings.LayerNorm.weight
+        fp = getattr(self, "_flat_param", None)
+        if (fp is not None and fp.grad is None) or (fp is None and probe.grad is None):
+            self._grad_flat.zero_()
+        if fp is not None:
+            fp.grad = self._grad_flat
+        with torch.cuda.device(self._device):
+            check(lib().mra_qformer_backward(self._handle, ptr(input_ids), ptr(attention_mask), ptr(enc), N, L, Kv, ptr(d_q), ptr(d_c),
+                                             ptr(self._grad_flat), ptr(self._train_ws), self._train_ws.numel(), current_stream()),
+                  "mra_qformer_backward")
+        self._bind_grads()
+        binder = getattr(self, "_extra_grad_binder", None)
+        if binder is not None:
+            binder()
+        # A backward is followed by an optimizer step sooner or later, and fused optimizers (torch._fused_adam_)
+        # update parameters WITHOUT bumping their version counters: presume the device copies stale from here on.
+        self._dirty = True
+
 
 # --------------------------------------------------------------------------------------------------
 # training (BASELINE config 5): forward with an activation tape + HIP backward behind torch.autograd
@@ -389,122 +496,3 @@ class _QFormerTrainFn(torch.autograd.Function):
         d_c = d_c.to(torch.float32).contiguous() if (ctx.want_cls and d_c is not None) else None
         owner._run_backward(input_ids, attention_mask, enc, N, L, Kv, d_q, d_c)
         return torch.zeros_like(owner._anchor), None, None, None, None, None
-
-
-def _qformer_enable_training(self: "QFormer") -> None:
-    """Allocate the flat gradient buffer, bind every ``bert.*`` parameter's ``.grad`` to its slice and build
-    the transposed weight copies (call again after changing weights; ``forward_train`` does it lazily)."""
-    self.sync_weights()
-    with torch.cuda.device(self._device):
-        check(lib().mra_qformer_enable_training(self._handle, current_stream()), "mra_qformer_enable_training")
-    if getattr(self, "_grad_flat", None) is None:
-        n = int(lib().mra_qformer_grad_bytes(self._handle)) // 4
-        self._grad_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
-        self._anchor = torch.zeros((), dtype=torch.float32, device=self._device, requires_grad=True)
-        self._train_ws = None
-        self._slices = {}
-        for k, p in self.bert.state_dict(prefix="bert.", keep_vars=True).items():
-            off, numel = C.c_size_t(), C.c_int64()
-            check(lib().mra_qformer_grad_offset(self._handle, k.encode(), C.byref(off), C.byref(numel)), f"grad_offset({k})")
-            self._slices[k] = (off.value // 4, int(numel.value), p)
-            p.requires_grad_(True)
-        # master weights: one flat f32 buffer in the gradient buffer's layout; every parameter becomes a view of
-        # it, so any optimizer updates it in place and mra_qformer_load_flat refreshes the device copies at once
-        self._master_flat = torch.zeros(n, dtype=torch.float32, device=self._device)
-        self._bind_master()
-
-
-def _qformer_bind_master(self: "QFormer") -> None:
-    """(Re-)point every ``bert.*`` parameter at its slice of the master buffer.  ``module.to()`` /
-    ``load_state_dict(assign=True)`` replace parameter storage; the current values are carried over."""
-    base = self._master_flat.data_ptr()
-    first = next(iter(self._slices.values()))
-    if first[2].data_ptr() == base + first[0] * 4 and getattr(self, "_master_bound", False):
-        return
-    with torch.no_grad():
-        for off, numel, p in self._slices.values():
-            view = self._master_flat[off: off + numel].view(p.shape)
-            if p.data_ptr() != view.data_ptr():
-                view.copy_(p.data)
-                p.data = view
-    self._master_bound = True
-
-
-def _qformer_grad_of(self: "QFormer", name: str) -> torch.Tensor:
-    """View of parameter ``name``'s gradient inside the flat buffer (ABI names, e.g. ``query_tokens``)."""
-    off, numel = C.c_size_t(), C.c_int64()
-    check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
-    return self._grad_flat[off.value // 4: off.value // 4 + numel.value]
-
-
-def _qformer_bind_grads(self: "QFormer") -> None:
-    probe = self.bert.embeddings.LayerNorm.weight
-    if probe.grad is not None and probe.grad.data_ptr() == self.grad_of("bert.embeddings.LayerNorm.weight").data_ptr():
-        return                                   # still bound from the previous backward
-    for off, numel, p in self._slices.values():
-        p.grad = self._grad_flat[off: off + numel].view(p.shape)
-
-
-def _qformer_forward_train(self: "QFormer", input_ids, attention_mask, enc, want_cls: bool = True):
-    """Training forward: ``(out_query [N,32,H], out_cls [N,H])`` connected to autograd.  ``loss.backward()``
-    accumulates parameter gradients (``p.grad`` of every ``bert.*`` parameter, ``grad_of('query_tokens')``)."""
-    self.enable_training()
-    cfg = self.cfg
-    enc = enc.to(cfg.op_dtype).contiguous()
-    if input_ids is not None:
-        input_ids = input_ids.to(device=enc.device, dtype=torch.int64).contiguous()
-    if attention_mask is not None:
-        attention_mask = attention_mask.to(device=enc.device, dtype=torch.int64).contiguous()
-    q, c = _QFormerTrainFn.apply(self._anchor, self, input_ids, attention_mask, enc, want_cls)
-    return (q, c) if want_cls else (q, None)
-
-
-def _qformer_slice_of(self: "QFormer", name: str):
-    off, numel = C.c_size_t(), C.c_int64()
-    check(lib().mra_qformer_grad_offset(self._handle, name.encode(), C.byref(off), C.byref(numel)), f"grad_offset({name})")
-    return off.value // 4, int(numel.value)
-
-
-def _qformer_flat_parameter(self: "QFormer") -> torch.nn.Parameter:
-    """ONE ``nn.Parameter`` over the whole master buffer with the whole gradient buffer as its ``.grad``: an
-    optimizer given this instead of the ~400 per-tensor parameters updates the Q-Former in one fused launch
-    (fused Adam over 186 M elements: 0.8 ms instead of 2.3 ms for the per-tensor lists).  The per-tensor
-    parameters stay valid views of the same memory (state_dict, checkpoints)."""
-    self.enable_training()
-    fp = getattr(self, "_flat_param", None)
-    if fp is None or fp.data_ptr() != self._master_flat.data_ptr():
-        fp = torch.nn.Parameter(self._master_flat, requires_grad=True)
-        object.__setattr__(self, "_flat_param", fp)      # not registered: it aliases the per-tensor parameters
-    fp.grad = self._grad_flat
-    return fp
-
-
-def _qformer_run_backward(self: "QFormer", input_ids, attention_mask, enc, N, L, Kv, d_q, d_c) -> None:
-    # optimizer.zero_grad(set_to_none=True) drops the views: start from a clean buffer in that case
-    probe = self.bert.embeddings.LayerNorm.weight
-    fp = getattr(self, "_flat_param", None)
-    if (fp is not None and fp.grad is None) or (fp is None and probe.grad is None):
-        self._grad_flat.zero_()
-    if fp is not None:
-        fp.grad = self._grad_flat
-    with torch.cuda.device(self._device):
-        check(lib().mra_qformer_backward(self._handle, ptr(input_ids), ptr(attention_mask), ptr(enc), N, L, Kv, ptr(d_q), ptr(d_c),
-                                         ptr(self._grad_flat), ptr(self._train_ws), self._train_ws.numel(), current_stream()),
-              "mra_qformer_backward")
-    self._bind_grads()
-    binder = getattr(self, "_extra_grad_binder", None)
-    if binder is not None:
-        binder()
-    # A backward is followed by an optimizer step sooner or later, and fused optimizers (torch._fused_adam_)
-    # update parameters WITHOUT bumping their version counters: presume the device copies stale from here on.
-    self._dirty = True
-
-
-QFormer.enable_training = _qformer_enable_training
-QFormer.grad_of = _qformer_grad_of
-QFormer._bind_grads = _qformer_bind_grads
-QFormer._bind_master = _qformer_bind_master
-QFormer.flat_parameter = _qformer_flat_parameter
-QFormer._slice_of = _qformer_slice_of
-QFormer.forward_train = _qformer_forward_train
-QFormer._run_backward = _qformer_run_backward
