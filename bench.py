@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold"],
+                    help="cross-attention formulation (auto = folded from Kv >= 2048)")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
     return ap.parse_args()
@@ -100,6 +102,8 @@ def main():
     # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
     model.kv_first = not args.no_kv_first
+    for m in ("video", "audio"):
+        getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = {m: torch.randn(n_local, kv[m], ENC_WIDTH[m], generator=g, device=dev, dtype=torch.float16) for m in ("video", "audio")}
     ids = torch.randint(1000, 30000, (n_local, L), generator=g, device=dev)

@@ -128,6 +128,15 @@ int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, v
  * K/V-projection launch, on the launch stream.  (NULL, NULL) switches it off. */
 int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
 
+/* How the six cross-attention layers are computed (HF modeling_instructblip.py:464-515 arithmetic either way):
+ *   1  K/V cache: K and V of every cross layer projected up front by one GEMM, then a flash-style core per layer;
+ *   2  folded:    per layer S = (Q W_k) enc^T, P = softmax(S / 8), context = (P enc) W_v^T + b_v -- half the flops
+ *                 at any Kv (the 32 queries are fewer than the 64 head dimensions), five launches per layer,
+ *                 scores kept in fp32;
+ *   0  automatic (default): folded from Kv >= 2048.
+ * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
+int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
+
 /* Scheduling hook: when `ev` (hipEvent_t as void*) is non-NULL every following mra_qformer_forward records it
  * right after its K/V-projection launch, on the launch stream.  The host side makes the light modality's
  * stream wait for the heavy modality's event, so the chip-filling GEMM runs alone and the two latency-bound

@@ -38,7 +38,7 @@ __device__ __forceinline__ long long view_off(const RowView& v, int m) {
 
 // XCD-contiguous remap (bijective for any grid size), group lookup, 8-row-tile panels
 template <int TN, int TM>
-__device__ __forceinline__ const GemmProb& pick_tile(const GemmArgs& args, int& n0, int& m0) {
+__device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int& m0) {
   int id = blockIdx.x;
   {
     const int nwg = args.total_tiles;
@@ -46,8 +46,17 @@ __device__ __forceinline__ const GemmProb& pick_tile(const GemmArgs& args, int& 
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
   const int g = (args.ngroups > 1 && id >= args.p[1].tile_begin) ? 1 : 0;
-  const GemmProb& P = args.p[g];
-  const int pid = id - P.tile_begin;
+  GemmProb P = args.p[g];
+  int pid = id - P.tile_begin;
+  if (P.batch > 1) {   // batch entry first, then the panel order inside it
+    const int per = P.mtiles * P.ntiles;
+    const int b = pid / per;
+    pid -= b * per;
+    P.A = (const char*)P.A + b * P.a_bs * 2;
+    P.W = (const char*)P.W + b * P.w_bs * 2;
+    P.C = (char*)P.C + b * P.c_bs_bytes;
+    if (P.bias) P.bias += (long long)b * P.bias_bs;
+  }
   constexpr int GM = 8;
   const int per_panel = GM * P.ntiles;
   const int panel = pid / per_panel;
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
   for (int i = 0; i < IW; ++i) {
     const int q = tid + i * NT;
     const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-    srcW[i] = (const char*)P.W + ((long long)(n0 + row) * K + c * 8) * 2;
+    srcW[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
   }
 #pragma unroll
   for (int i = 0; i < IX; ++i) {
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       const int q = lt + (i & 7) * 256;  // chunk inside the operand tile (2048 chunks each)
       const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
       if (i < 8) {
-        src[i] = (const char*)P.W + ((long long)(n0 + row) * K + c * 8) * 2;
+        src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
       } else {
         const int m = min(m0 + row, M - 1);
         src[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_k128_kernel(const GemmArgs
   for (int i = 0; i < IW; ++i) {
     const int q = tid + i * NT;
     const int row = q >> 4, c = (q & 15) ^ (row & 15);
-    srcW[i] = (const char*)P.W + ((long long)(n0 + row) * K + c * 8) * 2;
+    srcW[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
   }
 #pragma unroll
   for (int i = 0; i < IX; ++i) {
@@ -566,6 +575,7 @@ void gemm_set_debug_buffer(unsigned long long* p) { g_dbg = p; }
 
 int gemm_pick_config(const GemmProb* probs, int ngroups) {
   if (g_force_cfg >= 0) return g_force_cfg;
+  if (probs[0].tile_cfg > 0) return probs[0].tile_cfg - 1;
   // Largest tile that still gives every CU work: 256 CUs; aim for >= 2 waves of workgroups
   // with the 64/128 tiles and >= 1 full wave with the 256 tile.
   int best = 0;
@@ -574,8 +584,8 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
     long long tiles = 0;
     bool ok = true;
     for (int g = 0; g < ngroups; ++g) {
-      if (probs[g].N % t) ok = false;
-      tiles += (long long)((probs[g].M + t - 1) / t) * (probs[g].N / t);
+      if (probs[g].N % t && !probs[g].n_ragged) ok = false;
+      tiles += (long long)((probs[g].M + t - 1) / t) * ((probs[g].N + t - 1) / t) * (probs[g].batch > 1 ? probs[g].batch : 1);
     }
     if (!ok) continue;
     const long long need = c == 2 ? 512 : (c == 1 ? 384 : 0);
@@ -598,15 +608,17 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     a.p[g] = probs[g];
     GemmProb& p = a.p[g];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
-    if (p.K % 64 || p.N % t) return -1;
+    if (p.K % 64 || (p.N % t && !p.n_ragged)) return -1;
+    if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
+    if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
     p.mtiles = (p.M + t - 1) / t;
-    p.ntiles = p.N / t;
+    p.ntiles = (p.N + t - 1) / t;
     p.tile_begin = tiles;
-    tiles += p.mtiles * p.ntiles;
+    tiles += p.mtiles * p.ntiles * (p.batch > 1 ? p.batch : 1);
   }
   if (ngroups == 1) a.p[1] = a.p[0];
   a.total_tiles = tiles;

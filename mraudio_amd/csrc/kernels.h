@@ -38,6 +38,15 @@ struct GemmProb {
   // EPI_KV: weight row n = (cl * 2 + kv) * hidden + head * 64 + d ; activation row m = item * kv_tokens + tok
   // destination element ((((cl * 2 + kv) * kv_items + item) * kv_heads + head) * kv_tokens + tok) * 64 + d
   int kv_tokens, kv_items, kv_heads;
+  // Batched launch (batch > 1): problem b uses A + b * a_bs, W + b * w_bs (elements), bias + b * bias_bs and
+  // C + b * c_bs_bytes; M, N, K and the row views are shared.  Tiles never straddle batch entries.
+  int batch;
+  long long a_bs, w_bs, c_bs_bytes;
+  int bias_bs;
+  // n_ragged: N need not be a multiple of the tile; weight rows past N - 1 are read from row N - 1 and their
+  // output columns are written anyway, so C rows must hold ceil(N / tile) * tile columns and bias must be null.
+  int n_ragged;
+  int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile for this launch (first problem decides)
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
 };
@@ -117,6 +126,14 @@ int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, h
 struct TrJob { const void* src; void* dst; int R, C, tile_begin, tiles_x; };
 int launch_transpose16_batch(const TrJob* jobs_dev, int njobs, int total_tiles, int op_dtype, hipStream_t stream);
 int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream);  // y += x
+
+// ---- folded cross-attention helpers (fold.hip) ------------------------------------------------------
+// P[row][0..kv) = softmax(scale * S[row][0..kv)) in the operand dtype, P[row][kv..kvp) = 0
+int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p, int rows, int kv, int kvp, float scale, int op_dtype,
+                        hipStream_t stream);
+// dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < ld_d; src [batch][R][C], dst [batch][C][ld_d]
+int launch_transpose_pad(const void* src, void* dst, int R, int C, int ld_d, long long src_bs, long long dst_bs, int batch, int op_dtype,
+                         hipStream_t stream);
 
 // ---- attention ------------------------------------------------------------------------------
 struct AttnArgs {

@@ -142,6 +142,8 @@ size_t layout_params(mra_qformer* h, char* base) {
 struct Work {
   float *hA32, *hB32, *pre32, *hC32, *part;
   char *hA16, *hB16, *qkv16, *ctx16, *qc16, *hC16, *ffn16, *kv16;
+  char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
+  float* s32;                      // scores [N][R][kvp]
   int nsplit;
   size_t bytes;
 };
@@ -162,7 +164,18 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.qc16 = cv.take<char>(N * Q * H, 2);
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
-  w.kv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
+  w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = nullptr;
+  w.s32 = nullptr;
+  if (h->ncross > 0 && use_fold(h, Kv)) {
+    const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
+    w.encT = cv.take<char>((size_t)N * E * kvp, 2);
+    w.qp16 = cv.take<char>((size_t)N * R * E, 2);
+    w.s32 = cv.take<float>((size_t)N * R * kvp);
+    w.p16 = cv.take<char>((size_t)N * R * kvp, 2);
+    w.u16 = cv.take<char>((size_t)N * R * E, 2);
+  } else {
+    w.kv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
+  }
   w.nsplit = attn_pick_split(N, c.heads, (int)Q, Kv);
   w.part = nullptr;  // grid-split attention partials live right behind `bytes` (set by the caller)
   w.bytes = cv.off;
@@ -235,6 +248,13 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
     return fail(MRA_ENOMEM, std::string("hipMalloc of parameter arena: ") + hipGetErrorString(e));
   }
   layout_params(h, h->arena);
+  if (h->ncross > 0) {
+    e = hipMalloc((void**)&h->arena_f, (size_t)h->ncross * c.hidden * c.enc_width * 2);
+    if (e != hipSuccess) {
+      mra_qformer_destroy(h);
+      return fail(MRA_ENOMEM, std::string("fold weight arena: ") + hipGetErrorString(e));
+    }
+  }
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
   for (auto& kv : h->params) {
@@ -260,6 +280,7 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
   if (h->arena_t) (void)hipFree(h->arena_t);
+  if (h->arena_f) (void)hipFree(h->arena_f);
   if (h->flat_segs) (void)hipFree(h->flat_segs);
   if (h->tr_jobs) (void)hipFree(h->tr_jobs);
   delete h;
@@ -282,6 +303,7 @@ int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t 
   if (rc) return chk(rc, "launch_convert");
   it->second.loaded = true;
   h->transposes_stale = true;
+  h->fold_stale = true;
   return MRA_OK;
 }
 
@@ -294,6 +316,7 @@ int mra_qformer_load_flat(mra_qformer* h, const float* master, size_t master_byt
   for (auto& kv : h->params)
     if (kv.first.rfind("bert.", 0) == 0) kv.second.loaded = true;
   h->transposes_stale = true;
+  h->fold_stale = true;
   return MRA_OK;
 }
 
@@ -393,8 +416,21 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
                            h->embb, c.ln_eps, w.hA32, w.hA16, nullptr, op, stream);
   if (rc) return chk(rc, "embed_ln");
 
-  // K/V of every cross layer in one GEMM, scattered head-major
-  if (h->ncross > 0) {
+  const bool fold = h->ncross > 0 && use_fold(h, kv);
+  const int R = c.heads * Q, kvp = fold_kvp(kv);
+  if (fold) {
+    // folded cross-attention: enc^T per item (the K-contiguous operand of P . enc), key weights regrouped per head
+    rc = launch_transpose_pad(enc, w.encT, kv, E, kvp, (long long)kv * E, (long long)E * kvp, N, op, stream);
+    if (rc) return chk(rc, "enc transpose");
+    if (h->fold_stale) {
+      for (int ci = 0; ci < h->ncross && !rc; ++ci)
+        rc = launch_transpose_pad((const char*)h->wkv + (size_t)(ci * 2) * H * E * esz, h->arena_f + (size_t)ci * H * E * esz, 64, E, 64,
+                                  (long long)64 * E, (long long)E * 64, c.heads, op, stream);
+      if (rc) return chk(rc, "key weight regroup");
+      h->fold_stale = false;
+    }
+  } else if (h->ncross > 0) {
+    // K/V of every cross layer in one GEMM, scattered head-major
     if (h->kv_ev0 && h->kv_ev1) (void)hipEventRecord(h->kv_ev0, stream);
     rc = kv_project(h, enc, N, kv, w.kv16, stream);
     if (rc) return chk(rc, "kv projection gemm");
@@ -462,6 +498,48 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       p.M = N * Q; p.N = H; p.K = H;
       rc = launch_gemm(&p, 1, EPI_OP, op, stream);
       if (rc) return chk(rc, "cross q gemm");
+      if (fold) {
+        const int ci = Lw.cross_index;
+        const bool timed = ci == 0 && h->kv_ev0 && h->kv_ev1;
+        if (timed) (void)hipEventRecord(h->kv_ev0, stream);
+        // 6a. Q' = Q_h W_k,h per head: [N*32, 64] x [E, 64]^T -> Q' [N][head*32 + q][E]
+        GemmProb d{};
+        d.A = w.qc16; d.a = qc_rows; d.a_bs = 64;
+        d.W = h->arena_f + (size_t)ci * H * E * esz; d.w_bs = (long long)E * 64;
+        d.C = w.qp16; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * esz;
+        d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = 1;
+        rc = launch_gemm(&d, 1, EPI_OP, op, stream);
+        if (rc) return chk(rc, "fold q' gemm");
+        // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, fp32, rows padded to kvp columns
+        GemmProb sc{};
+        sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
+        sc.W = enc; sc.w_bs = (long long)kv * E;
+        sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;
+        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1; sc.tile_cfg = 2;
+        rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
+        if (rc) return chk(rc, "fold scores gemm");
+        // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
+        rc = launch_softmax_rows(w.s32, kvp, w.p16, kvp, N * R, kv, kvp, 0.125f, op, stream);
+        if (rc) return chk(rc, "fold softmax");
+        // 6d. U[n] = P[n] enc[n]: [R, kvp] x [E, kvp]^T per item
+        GemmProb pv{};
+        pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
+        pv.W = w.encT; pv.w_bs = (long long)E * kvp;
+        pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
+        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N; pv.tile_cfg = 2;
+        rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
+        if (rc) return chk(rc, "fold p.enc gemm");
+        // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]
+        GemmProb cx{};
+        cx.A = w.u16; cx.a = items_view((long long)R * E, Q, E); cx.a_bs = (long long)Q * E;
+        cx.W = (const char*)h->wkv + (size_t)(ci * 2 + 1) * H * E * esz; cx.w_bs = (long long)64 * E;
+        cx.bias = h->bkv + (size_t)(ci * 2 + 1) * H; cx.bias_bs = 64;
+        cx.C = w.ctx16; cx.c = qc_rows; cx.c_bs_bytes = 64 * esz;
+        cx.M = N * Q; cx.N = 64; cx.K = E; cx.batch = c.heads; cx.tile_cfg = 1;
+        rc = launch_gemm(&cx, 1, EPI_OP, op, stream);
+        if (rc) return chk(rc, "fold context gemm");
+        if (timed) (void)hipEventRecord(h->kv_ev1, stream);
+      } else {
       // 6. cross-attention core over the head-major K/V cache
       AttnArgs a{};
       const size_t per_sel = (size_t)N * c.heads * kv * 64;
@@ -478,6 +556,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       a.scale = 0.125f; a.nsplit = w.nsplit; a.part = w.part;
       rc = launch_attention(a, op, stream);
       if (rc) return chk(rc, "cross attention");
+      }
       // 7. output projection + residual (hB[:, :32]), 8. LayerNorm -> hC (compact)
       GemmProb o{};
       o.A = w.ctx16; o.a = qc_rows;
@@ -584,6 +663,13 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
   if ((ev_start == nullptr) != (ev_stop == nullptr)) return fail(MRA_EINVAL, "give both events or neither");
   h->kv_ev0 = reinterpret_cast<hipEvent_t>(ev_start);
   h->kv_ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
+  return MRA_OK;
+}
+
+int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache) or 2 (folded)");
+  h->cross_mode = mode;
   return MRA_OK;
 }
 

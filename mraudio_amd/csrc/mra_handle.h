@@ -85,6 +85,10 @@ struct mra_qformer {
   float* bkv = nullptr;
   void* wllm = nullptr;
   float* bllm = nullptr;
+  // folded cross-attention (mra_qformer_set_cross_mode): per cross layer the key weight regrouped as [heads][E][64]
+  char* arena_f = nullptr;
+  bool fold_stale = true;
+  int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
   hipEvent_t kv_done = nullptr;                   // optional scheduling hook (mra_qformer_set_kv_done_event)
   hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
   // training
@@ -99,6 +103,9 @@ struct mra_qformer {
 };
 
 namespace mra_host {
+// folded cross-attention pays once the encoder sequence is long (fewer flops at any Kv, but five launches per layer)
+inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
+inline int fold_kvp(int kv) { return (kv + 127) / 128 * 128; }
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);
 }  // namespace mra_host

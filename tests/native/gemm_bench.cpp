@@ -43,6 +43,12 @@ int main(int argc, char** argv) {
       {"ffn-up 2048x768->3072 cfg0", 2048, 3072, 768, EPI_GELU_OP, 0},
       {"ffn-down 2048x3072->768", 2048, 768, 3072, EPI_RES_F32, -1},
       {"ffn-down 2048x3072->768 cfg1", 2048, 768, 3072, EPI_RES_F32, 1},
+      // proxies for the folded cross-attention: scores enc . Q'^T and P . enc per layer, all 32 items
+      {"fold scores N384 128-tile", 32 * 8224, 384, 1408, EPI_OP, 1},
+      {"fold scores N512 256-tile", 32 * 8224, 512, 1408, EPI_OP, 2},
+      {"fold scores N512 f32 out", 32 * 8224, 512, 1408, EPI_F32, 2},
+      {"fold P.enc M12288 N1408 K8256 128", 32 * 384, 1408, 8256, EPI_OP, 1},
+      {"fold P.enc M16384 N1536 K8256 256", 32 * 512, 1536, 8256, EPI_OP, 2},
   };
   size_t maxA = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) {
@@ -67,7 +73,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&bias, 16384 * 4));
   CK(hipMemset(bias, 0, 16384 * 4));
   CK(hipMalloc((void**)&R, (size_t)2048 * 768 * 4));
-  CK(hipMemset(R, 0, (size_t)2048 * 768 * 4));
+  CK(hipMemset(R, 0, (size_t)2048 * 768 * 4));  // only the EPI_RES_F32 shapes (M <= 2048, N = 768) read it
   CK(hipMalloc((void**)&C, maxC * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

@@ -307,6 +307,46 @@ static void test_attention(int op, int items, int heads, int q_rows, int kv_len,
   report(name, worst, op == OP_F16 ? 3e-3 : 2e-2);
 }
 
+// batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
+static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
+  gemm_force_config(-1);
+  const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
+  const int ldc = (N + t - 1) / t * t;                       // C rows hold whole tiles
+  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * N * K);
+  for (auto& v : A) v = to_op(frand(), op);
+  for (auto& v : W) v = to_op(frand(0.05f), op);
+  std::vector<float> bias((size_t)batch * N);
+  for (auto& v : bias) v = ragged ? 0.f : frand(0.5f);
+  Dev<uint16_t> dA(A), dW(W), dC16((size_t)batch * M * ldc);
+  Dev<float> dB(bias), dC32((size_t)batch * M * ldc);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = ragged ? nullptr : dB.p;
+  p.M = M; p.N = N; p.K = K;
+  p.batch = batch; p.a_bs = (long long)M * K; p.w_bs = (long long)N * K; p.bias_bs = N;
+  p.n_ragged = ragged ? 1 : 0; p.tile_cfg = cfg + 1;
+  const bool f32 = epi == EPI_F32;
+  p.C = f32 ? (void*)dC32.p : (void*)dC16.p; p.c = RowView{0, M, ldc};
+  p.c_bs_bytes = (long long)M * ldc * (f32 ? 4 : 2);
+  const int rc = launch_gemm(&p, 1, epi, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> c16 = dC16.get();
+  std::vector<float> c32 = dC32.get();
+  double worst = rc ? 1e30 : 0;
+  for (int b = 0; b < batch && !rc; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        double acc = bias[(size_t)b * N + n];
+        for (int k = 0; k < K; ++k) acc += (double)from_op(A[((size_t)b * M + m) * K + k], op) * from_op(W[((size_t)b * N + n) * K + k], op);
+        const size_t ci = ((size_t)b * M + m) * ldc + n;
+        const double got = f32 ? c32[ci] : from_op(c16[ci], op);
+        worst = std::max(worst, fabs(got - acc) / (1 + fabs(acc)));
+      }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm batched cfg%d epi%d M%d N%d K%d x%d%s", cfg, epi, M, N, K, batch, ragged ? " ragged-N" : "");
+  report(name, worst, f32 ? 2e-4 : 3e-3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-gradient GEMM dW = dY^T X (+ bias gradient), row-major and head-major dY, ragged M, accumulate
 static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accumulate) {
@@ -780,6 +820,11 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  test_gemm_batched(1, EPI_F32, OP_F16, 96, 300, 192, 3, true);     // scores: M = 3 x 32 rows, N = kv ragged
+  test_gemm_batched(1, EPI_OP, OP_F16, 96, 256, 320, 3, false);     // P . enc^T
+  test_gemm_batched(0, EPI_OP, OP_F16, 70, 128, 64, 4, false);      // per-head projections, K = 64
+  test_gemm_batched(0, EPI_F32, OP_BF16, 33, 100, 128, 2, true);
+  test_gemm_batched(2, EPI_F32, OP_F16, 300, 700, 128, 2, true);
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);

@@ -312,3 +312,40 @@ def test_bf16_operands_run_and_are_close(dev):
     ref = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(2, -1, -1), O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]))[:, :32]
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 2e-2, rel  # bf16 has 8 significand bits: ~8x the f16 error; f16 is the default for that reason
+
+
+def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, dev):
+    """The folded cross-attention (S = (Q W_k) enc^T, ctx = (P enc) W_v^T + b_v; automatic from Kv >= 2048) is the
+    same arithmetic re-associated: forced on at small and ragged Kv it must agree with the K/V-cache path and with
+    the oracle to the usual bar, and the automatic switch must pick it for a long sequence."""
+    for (qf, cfg, w), kv, n, L in ((video, 257, 3, 9), (audio, 100, 2, 5), (video, 130, 2, 4)):
+        ocfg = oracle_cfg(cfg)
+        ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 11, True)
+        enc = qf.modality_ln(feats.to(dev))
+        qf.set_cross_mode("kv_cache")
+        ref = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
+        qf.set_cross_mode("fold")
+        got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
+        qf.set_cross_mode("auto")
+        assert (got["query"] - ref["query"]).abs().max().item() < 5e-3, (kv, (got["query"] - ref["query"]).abs().max().item())
+        assert (got["cls"] - ref["cls"]).abs().max().item() < 5e-3
+        enc_ref = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"])
+        h = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(n, -1, -1), enc_ref)
+        assert (got["query"].cpu() - h[:, :32]).abs().max().item() < Z_ATOL
+        rel = ((got["query"].cpu() - h[:, :32]).norm() / h[:, :32].norm()).item()
+        assert rel < 2e-3, rel
+    # long sequence: automatic = folded; against the cache path on the same inputs
+    qf, cfg, w = video
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, 2100, 1408, generator=g)
+    ids = torch.randint(1000, 30000, (2, 7), generator=g)
+    att = torch.ones(2, 39, dtype=torch.long)
+    enc = qf.modality_ln(feats.to(dev))
+    auto = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    qf.set_cross_mode("kv_cache")
+    ref = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    qf.set_cross_mode("fold")
+    forced = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    qf.set_cross_mode("auto")
+    assert torch.equal(auto, forced)
+    assert (auto - ref).abs().max().item() < 5e-3
