@@ -134,6 +134,7 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
  *                 at any Kv (the 32 queries are fewer than the 64 head dimensions), five launches per layer,
  *                 scores kept in fp32;
  *   0  automatic (default): folded from Kv >= 2048.
+ *   3  as 2 with the 128 x 384 loader-wave tile instead of the 128 x 128 tiles (A/B runs: no faster).
  * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
 

@@ -297,12 +297,15 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // MFMAs between barriers; a loader issues tile kt+1 right after barrier kt and parks on vmcnt(0) until
 // barrier kt+1, off the compute waves' critical path.  Three waves per SIMD cap the kernel at 168
 // VGPRs: fragments are read just in time (all four B fragments, A one at a time).
-template <typename T, int EPI, bool NODMA = false>  // NODMA: diagnostic only (wrong results): loaders stop after tile 1
+// TN x TM = 256 x 256 (K/V projection) or 128 x 384 (the folded cross-attention's batched GEMMs: all 384
+// (head, query) rows of an item against a 128-row slab of the other operand, so that operand streams once).
+template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256>  // NODMA: diagnostic only (wrong results)
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
-  constexpr int TN = 256, TM = 256, BK = 64, ROWB = BK * 2;
-  constexpr int WGM = 4, WTN = 128, WTM = 64, FN = 8, FM = 4;
+  constexpr int BK = 64, ROWB = BK * 2;
+  constexpr int WGM = 4, WTN = TN / 2, WTM = TM / 4, FN = WTN / 16, FM = WTM / 16;
   constexpr int BUF = (TN + TM) * ROWB;
-  constexpr int NLD = 16;  // LDS-DMA instructions per loader lane per K tile: 4096 chunks / 256 lanes
+  constexpr int NLW = TN * 8 / 256, NLD = (TN + TM) * 8 / 256;  // LDS-DMA instructions per loader lane per K tile (W rows first)
+  static_assert(TN % 32 == 0 && TM % 64 == 0 && NLD * 256 == (TN + TM) * 8, "tile must split over 2 x 4 waves and 256 loader lanes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -318,9 +321,9 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     const char* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int q = lt + (i & 7) * 256;  // chunk inside the operand tile (2048 chunks each)
+      const int q = lt + (i < NLW ? i : i - NLW) * 256;  // chunk inside the operand tile
       const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-      if (i < 8) {
+      if (i < NLW) {
         src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
       } else {
         const int m = min(m0 + row, M - 1);
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       const long long koff = (long long)kt * ROWB;
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        glds16(src[i] + koff, base + (i < 8 ? 0 : TN * ROWB) + (wq0 + (i & 7) * 256) * 16);
+        glds16(src[i] + koff, base + (i < NLW ? 0 : TN * ROWB) + (wq0 + (i < NLW ? i : i - NLW) * 256) * 16);
     };
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -531,6 +534,16 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
   MRA_EPI_SWITCH((launch_k(gemm_ws_kernel<T, E>, a, 768, lds, stream)))
 }
 
+template <typename T>
+int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (weight rows) x 384 (activation rows)
+  constexpr size_t lds = 2 * (128 + 384) * 128;
+  switch (epi) {
+    case EPI_OP: return launch_k(gemm_ws_kernel<T, EPI_OP, false, 128, 384>, a, 768, lds, stream);
+    case EPI_F32: return launch_k(gemm_ws_kernel<T, EPI_F32, false, 128, 384>, a, 768, lds, stream);
+    default: return -2;
+  }
+}
+
 template <typename T, int TN, int TM, int WGN, int WGM>
 int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
   constexpr size_t lds = 2 * (TN + TM) * 256;
@@ -543,6 +556,7 @@ int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
 
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
+  if (cfg == 3) return launch_ws_fold<T>(a, epi, stream);
 #ifdef MRA_GEMM_EXPERIMENTS
   if (g_variant != 5 && g_variant != 1) {
     const int rc = launch_experiment<T>(a, cfg, epi, g_variant, stream);
@@ -565,6 +579,8 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
 }
 
 constexpr int kTile[3] = {64, 128, 256};
+constexpr int kTileN[4] = {64, 128, 256, 128};   // weight rows per tile
+constexpr int kTileM[4] = {64, 128, 256, 384};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
 
 }  // namespace
 
@@ -600,7 +616,8 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
   if (ngroups < 1 || ngroups > 2) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
-  const int t = kTile[cfg];
+  if (cfg < 0 || cfg > 3) return -1;
+  const int t = kTileN[cfg], tm = kTileM[cfg];
   GemmArgs a;
   a.ngroups = ngroups;
   int tiles = 0;
@@ -615,7 +632,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
-    p.mtiles = (p.M + t - 1) / t;
+    p.mtiles = (p.M + tm - 1) / tm;
     p.ntiles = (p.N + t - 1) / t;
     p.tile_begin = tiles;
     tiles += p.mtiles * p.ntiles * (p.batch > 1 ? p.batch : 1);

@@ -46,7 +46,8 @@ struct GemmProb {
   // n_ragged: N need not be a multiple of the tile; weight rows past N - 1 are read from row N - 1 and their
   // output columns are written anyway, so C rows must hold ceil(N / tile) * tile columns and bias must be null.
   int n_ragged;
-  int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile for this launch (first problem decides)
+  int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
+                   // rows) loader-wave tile (EPI_OP / EPI_F32 only); the first problem decides
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
 };

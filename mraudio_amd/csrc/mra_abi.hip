@@ -515,7 +515,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
         sc.W = enc; sc.w_bs = (long long)kv * E;
         sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;
-        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1; sc.tile_cfg = 2;
+        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1; sc.tile_cfg = R == 384 ? h->fold_tile : 2;
         rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
         if (rc) return chk(rc, "fold scores gemm");
         // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
@@ -526,7 +526,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
         pv.W = w.encT; pv.w_bs = (long long)E * kvp;
         pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
-        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N; pv.tile_cfg = 2;
+        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N; pv.tile_cfg = R == 384 ? h->fold_tile : 2;
         rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold p.enc gemm");
         // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]
@@ -668,8 +668,9 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
 
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode) {
   if (!h) return fail(MRA_EINVAL, "null handle");
-  if (mode < 0 || mode > 2) return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache) or 2 (folded)");
-  h->cross_mode = mode;
+  if (mode < 0 || mode > 3) return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache), 2 (folded) or 3 (folded, 128x384 tiles)");
+  h->cross_mode = mode == 3 ? 2 : mode;
+  h->fold_tile = mode == 3 ? 4 : 2;
   return MRA_OK;
 }
 

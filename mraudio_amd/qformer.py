@@ -350,7 +350,7 @@ class QFormer(nn.Module):
     def set_cross_mode(self, mode) -> None:
         """How the cross-attention layers run: ``"auto"`` (folded from Kv >= 2048), ``"kv_cache"`` or ``"fold"``
         (``mra_qformer_set_cross_mode``).  Same arithmetic, re-associated; the workspace size follows the mode."""
-        code = {"auto": 0, "kv_cache": 1, "fold": 2}.get(mode, mode)
+        code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3}.get(mode, mode)
         check(lib().mra_qformer_set_cross_mode(self._handle, int(code)), "mra_qformer_set_cross_mode")
 
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
