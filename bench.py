@@ -118,6 +118,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # lazy one-time work (workspace growth in the caching allocator, first-launch kernel attributes, per-head
+    # weight regrouping of the folded path, event creation, clock ramp) belongs to set-up, not to the W warm-up steps
+    for _ in range(3):
+        step()
+    fence()
     log(f"rank {rank}/{world}: model ready, {n_local} clips/GPU, kv {kv}")
     for _ in range(args.warmup):
         out = step()
@@ -183,6 +188,12 @@ def main():
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
+    fold_pmc = os.path.join(ROOT, "profiles", "r01g_pmc_fold.json")
+    traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
+    if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
+        traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
+        traffic_src = "profiles/r01g_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
+
     flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
 
     # ---- the encode stage (row A1), timed SEPARATELY: stock PyTorch EVA ViT-g over every frame of the step ----
@@ -217,7 +228,7 @@ def main():
                           "kernel": "folded cross-attention of one layer, video: per-head Q' GEMM + batched scores GEMM (128x128 tiles, fp32 rows) + "
                                     "softmax rows + batched P.enc GEMM + per-head context GEMM (5 launches, cross layer 0 of 6)",
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": None,
+                          "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                           "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_alg,
                           "note": "achieved = algorithmic flops of the layer in the reference formulation (K/V projection of every token + attention "
                                   "core) / measured duration of the block; executed_tflops counts the re-associated products actually run",
@@ -229,7 +240,7 @@ def main():
                          {"bound": "mfma", "kernel": "gemm_ws_kernel<256x256x64, EPI_KV> (K/V projection of all cross layers, video)",
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                          "traffic_source": "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None,
+                          "traffic_source": traffic_src,
                           "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": kv_flops,
                           "standalone_launch_ms": round(kv_ms, 4), "standalone_tflops": round(kv_flops / (kv_ms * 1e-3) / 1e12, 1)}),
             "cpu_baseline": cpu,
