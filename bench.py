@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold384"],
                     help="cross-attention formulation (auto = folded from Kv >= 2048)")
+    ap.add_argument("--item-groups", type=int, default=1, help="item groups of a long-sequence Q-Former on separate streams (1 = off)")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
     return ap.parse_args()
@@ -102,6 +103,7 @@ def main():
     # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
     model.kv_first = not args.no_kv_first
+    model.item_groups = args.item_groups
     for m in ("video", "audio"):
         getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -132,18 +134,25 @@ def main():
     # the library on the launch stream (= torch's current stream)
     lib = _lib.lib()
     qf = model.video_Qformer
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in evs:   # create the underlying hipEvents (torch creates them lazily on first record)
-        a.record(); b.record()
+    # one (start, stop) pair per item group and step; with G groups the G blocks of cross layer 0 run concurrently on G
+    # streams, so the measured duration is the span from the first group's start to the last group's stop
+    G = max(1, args.item_groups)
+    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(G)] for _ in range(args.steps)]
+    for pairs in evs:   # create the underlying hipEvents (torch creates them lazily on first record)
+        for a, b in pairs:
+            a.record(); b.record()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        _lib.check(lib.mra_qformer_set_kv_events(qf._handle, evs[i][0].cuda_event, evs[i][1].cuda_event), "set_kv_events")
+        model.roofline_events = {"video": evs[i]}
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    _lib.check(lib.mra_qformer_set_kv_events(qf._handle, None, None), "set_kv_events")
-    kv_step_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    model.roofline_events = None
+
+    def span(pairs):   # pairs a step did not use keep their creation-time record: negative, never the maximum
+        return max(pairs[0][0].elapsed_time(b) for _, b in pairs)
+    kv_step_ms = sum(span(p) for p in evs) / len(evs)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -137,6 +137,10 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
  *   3  as 2 with the 128 x 384 loader-wave tile instead of the 128 x 128 tiles (A/B runs: no faster).
  * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
+/* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
+ * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one
+ * handle concurrently on different streams (item groups, mraudio_amd/qformer.py) calls it once before forking. */
+int mra_qformer_prepare(mra_qformer* h, void* stream);
 
 /* Scheduling hook: when `ev` (hipEvent_t as void*) is non-NULL every following mra_qformer_forward records it
  * right after its K/V-projection launch, on the launch stream.  The host side makes the light modality's

@@ -422,13 +422,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
     // folded cross-attention: enc^T per item (the K-contiguous operand of P . enc), key weights regrouped per head
     rc = launch_transpose_pad(enc, w.encT, kv, E, kvp, (long long)kv * E, (long long)E * kvp, N, op, stream);
     if (rc) return chk(rc, "enc transpose");
-    if (h->fold_stale) {
-      for (int ci = 0; ci < h->ncross && !rc; ++ci)
-        rc = launch_transpose_pad((const char*)h->wkv + (size_t)(ci * 2) * H * E * esz, h->arena_f + (size_t)ci * H * E * esz, 64, E, 64,
-                                  (long long)64 * E, (long long)E * 64, c.heads, op, stream);
-      if (rc) return chk(rc, "key weight regroup");
-      h->fold_stale = false;
-    }
+    if ((rc = mra_qformer_prepare(h, stream_))) return rc;
   } else if (h->ncross > 0) {
     // K/V of every cross layer in one GEMM, scattered head-major
     if (h->kv_ev0 && h->kv_ev1) (void)hipEventRecord(h->kv_ev0, stream);
@@ -663,6 +657,20 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
   if ((ev_start == nullptr) != (ev_stop == nullptr)) return fail(MRA_EINVAL, "give both events or neither");
   h->kv_ev0 = reinterpret_cast<hipEvent_t>(ev_start);
   h->kv_ev1 = reinterpret_cast<hipEvent_t>(ev_stop);
+  return MRA_OK;
+}
+
+int mra_qformer_prepare(mra_qformer* h, void* stream) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (!h->fold_stale || h->ncross == 0) return MRA_OK;
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, E = c.enc_width, esz = 2;
+  for (int ci = 0; ci < h->ncross; ++ci) {   // W_k [H][E] of cross layer ci -> [heads][E][64]
+    const int rc = launch_transpose_pad((const char*)h->wkv + (size_t)(ci * 2) * H * E * esz, h->arena_f + (size_t)ci * H * E * esz, 64, (int)E,
+                                        64, (long long)64 * E, (long long)E * 64, c.heads, h->op(), as_stream(stream));
+    if (rc) return chk(rc, "key weight regroup");
+  }
+  h->fold_stale = false;
   return MRA_OK;
 }
 

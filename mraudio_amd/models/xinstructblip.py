@@ -134,6 +134,9 @@ class XInstructBLIP(nn.Module):
         self.clip_parallel = True
         self.overlap_modalities = overlap_modalities
         self.kv_first = True             # see fuse_score: light modalities wait for the heavy K/V projection
+        self.item_groups = 1             # see fuse_score: item groups of a long-sequence Q-Former on separate streams (off:
+                                         # the host cannot issue G x 250 launches per step fast enough)
+        self.roofline_events = None      # bench instrumentation: {modality: [(start, stop) events per item group]}
         self._streams: Dict[str, torch.cuda.Stream] = {}
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.tokenizer = tokenizer if tokenizer is not None else self.init_tokenizer(truncation_side="left")
@@ -360,7 +363,10 @@ class XInstructBLIP(nn.Module):
                     side.wait_event(heavy_done)
             with torch.cuda.stream(side):
                 enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
-                res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True)
+                # long sequences (folded cross-attention): independent item groups on the Q-Former's group streams
+                groups = self.item_groups if (int(enc.shape[1]) >= 2048 and n_local >= 2 * self.item_groups) else 1
+                res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True, item_groups=groups,
+                                       kv_events=(self.roofline_events or {}).get(m))
                 z = self._gather(res["query"], n)
                 cls = self._gather(res["cls"], n)
                 sim, logit = scorer.cosine_scores(z, cls)

@@ -349,3 +349,20 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
     qf.set_cross_mode("auto")
     assert torch.equal(auto, forced)
     assert (auto - ref).abs().max().item() < 5e-3
+
+
+def test_item_groups_give_identical_results(video, dev):
+    """Items never interact, so running contiguous item blocks as separate forwards of the same handle on the group
+    streams (``item_groups``) must reproduce the single-launch-sequence outputs bit for bit, in both cross modes."""
+    qf, cfg, w = video
+    ocfg = oracle_cfg(cfg)
+    ids, tmask, att, feats = make_inputs(ocfg, 7, 6, 150, 21, True)
+    enc = qf.modality_ln(feats.to(dev))
+    for mode in ("kv_cache", "fold"):
+        qf.set_cross_mode(mode)
+        one = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_full=True, want_cls=True)
+        for G in (2, 3, 7, 9):
+            many = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_full=True, want_cls=True, item_groups=G)
+            for k in ("query", "full", "cls"):
+                assert torch.equal(one[k], many[k]), (mode, G, k)
+    qf.set_cross_mode("auto")
