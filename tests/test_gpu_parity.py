@@ -318,7 +318,7 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
     """The folded cross-attention (S = (Q W_k) enc^T, ctx = (P enc) W_v^T + b_v; automatic from Kv >= 2048) is the
     same arithmetic re-associated: forced on at small and ragged Kv it must agree with the K/V-cache path and with
     the oracle to the usual bar, and the automatic switch must pick it for a long sequence."""
-    for (qf, cfg, w), kv, n, L in ((video, 257, 3, 9), (audio, 100, 2, 5), (video, 130, 2, 4)):
+    for (qf, cfg, w), kv, n, L in ((video, 257, 3, 9), (audio, 100, 2, 5), (video, 130, 2, 4), (video, 200, 7, 4)):   # 7 items: two item groups
         ocfg = oracle_cfg(cfg)
         ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 11, True)
         enc = qf.modality_ln(feats.to(dev))
