@@ -299,13 +299,16 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // VGPRs: fragments are read just in time (all four B fragments, A one at a time).
 // TN x TM = 256 x 256 (K/V projection) or 128 x 384 (the folded cross-attention's batched GEMMs: all 384
 // (head, query) rows of an item against a 128-row slab of the other operand, so that operand streams once).
-template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256>  // NODMA: diagnostic only (wrong results)
+// 176 x 384 with the 8 compute waves in one column (WGM = 8): P . enc of the folded path -- N = 1408 = 8 x 176, so
+// 32 items give exactly 256 workgroups, one per CU, and each streams its 176-row slab of enc^T exactly once.
+template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4>  // NODMA: diagnostic only (wrong results)
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int BK = 64, ROWB = BK * 2;
-  constexpr int WGM = 4, WTN = TN / 2, WTM = TM / 4, FN = WTN / 16, FM = WTM / 16;
+  constexpr int WGN = 8 / WGM, WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
   constexpr int BUF = (TN + TM) * ROWB;
-  constexpr int NLW = TN * 8 / 256, NLD = (TN + TM) * 8 / 256;  // LDS-DMA instructions per loader lane per K tile (W rows first)
-  static_assert(TN % 32 == 0 && TM % 64 == 0 && NLD * 256 == (TN + TM) * 8, "tile must split over 2 x 4 waves and 256 loader lanes");
+  constexpr int NCHUNK = (TN + TM) * 8, NLD = (NCHUNK + 255) / 256;  // 16-byte chunks of a K tile (W rows, then A rows) / loader lanes
+  constexpr bool STAGED = (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) && TN % 64 == 0;   // LDS-staged 16-bit epilogue
+  static_assert(WTN % 16 == 0 && WTM % 16 == 0 && TN % 16 == 0 && NCHUNK % 64 == 0, "tile must split over the waves; whole waves per DMA piece");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -321,12 +324,12 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     const char* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int q = lt + (i < NLW ? i : i - NLW) * 256;  // chunk inside the operand tile
+      const int q = min(lt + i * 256, NCHUNK - 1);   // chunk of the K tile: rows [0, TN) are W, [TN, TN + TM) are A (TN % 16 == 0)
       const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-      if (i < NLW) {
+      if (row < TN) {
         src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
       } else {
-        const int m = min(m0 + row, M - 1);
+        const int m = min(m0 + row - TN, M - 1);
         src[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
       }
     }
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       const long long koff = (long long)kt * ROWB;
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        glds16(src[i] + koff, base + (i < NLW ? 0 : TN * ROWB) + (wq0 + (i < NLW ? i : i - NLW) * 256) * 16);
+        if (i * 256 + wq0 < NCHUNK) glds16(src[i] + koff, base + (wq0 + i * 256) * 16);   // wave-uniform: whole 64-chunk pieces
     };
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       asm volatile("" ::: "memory");
       if (kt + 1 < nk && !(NODMA && kt >= 1)) stage((kt + 1) & 1, kt + 1);
     }
-    if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+    if constexpr (STAGED) {
       __syncthreads();  // K loop reads over
       __syncthreads();  // tile staged in LDS by the compute waves
     }
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       }
     }
   }
-  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+  if constexpr (STAGED) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
@@ -544,6 +547,13 @@ int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (w
   }
 }
 
+template <typename T>
+int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (weight rows) x 384 (activation rows), 1 x 8 waves
+  constexpr size_t lds = 2 * (176 + 384) * 128;
+  if (epi != EPI_OP) return -2;
+  return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8>, a, 768, lds, stream);
+}
+
 template <typename T, int TN, int TM, int WGN, int WGM>
 int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
   constexpr size_t lds = 2 * (TN + TM) * 256;
@@ -557,6 +567,7 @@ int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
   if (cfg == 3) return launch_ws_fold<T>(a, epi, stream);
+  if (cfg == 4) return launch_ws_pv<T>(a, epi, stream);
 #ifdef MRA_GEMM_EXPERIMENTS
   if (g_variant != 5 && g_variant != 1) {
     const int rc = launch_experiment<T>(a, cfg, epi, g_variant, stream);
@@ -579,8 +590,8 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
 }
 
 constexpr int kTile[3] = {64, 128, 256};
-constexpr int kTileN[4] = {64, 128, 256, 128};   // weight rows per tile
-constexpr int kTileM[4] = {64, 128, 256, 384};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
+constexpr int kTileN[5] = {64, 128, 256, 128, 176};   // weight rows per tile
+constexpr int kTileM[5] = {64, 128, 256, 384, 384};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
 
 }  // namespace
 
@@ -616,7 +627,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
   if (ngroups < 1 || ngroups > 2) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
-  if (cfg < 0 || cfg > 3) return -1;
+  if (cfg < 0 || cfg > 4) return -1;
   const int t = kTileN[cfg], tm = kTileM[cfg];
   GemmArgs a;
   a.ngroups = ngroups;

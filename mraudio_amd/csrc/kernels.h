@@ -47,7 +47,8 @@ struct GemmProb {
   // output columns are written anyway, so C rows must hold ceil(N / tile) * tile columns and bias must be null.
   int n_ragged;
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
-                   // rows) loader-wave tile (EPI_OP / EPI_F32 only); the first problem decides
+                   // rows) loader-wave tile (EPI_OP / EPI_F32 only), 5 = 176 x 384 with the compute waves in one column (EPI_OP only,
+                   // N % 176 == 0); the first problem decides
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
 };

@@ -12,6 +12,7 @@
 //   * residual stream, LayerNorm statistics and softmax are fp32; only MFMA operands are f16/bf16.
 // No allocation and no synchronisation after create/load; everything is enqueued on `stream`.
 #include <cstdio>
+#include <cstdlib>
 
 #include "mra_handle.h"
 
@@ -255,6 +256,7 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
       return fail(MRA_ENOMEM, std::string("fold weight arena: ") + hipGetErrorString(e));
     }
   }
+  if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);   // A/B runs: 2 = 128 x 128 tiles for P . enc
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
   for (auto& kv : h->params) {
@@ -520,7 +522,8 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
         pv.W = w.encT; pv.w_bs = (long long)E * kvp;
         pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
-        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N; pv.tile_cfg = R == 384 ? h->fold_tile : 2;
+        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N;
+        pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
         rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold p.enc gemm");
         // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]

@@ -88,6 +88,7 @@ struct mra_qformer {
   // folded cross-attention (mra_qformer_set_cross_mode): per cross layer the key weight regrouped as [heads][E][64]
   char* arena_f = nullptr;
   bool fold_stale = true;
+  int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
   int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
   hipEvent_t kv_done = nullptr;                   // optional scheduling hook (mra_qformer_set_kv_done_event)

@@ -310,7 +310,7 @@ static void test_attention(int op, int items, int heads, int q_rows, int kv_len,
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
   gemm_force_config(-1);
-  const int t = cfg == 0 ? 64 : (cfg == 2 ? 256 : 128);      // weight rows per tile (config 3: 128 x 384)
+  const int t = cfg == 0 ? 64 : (cfg == 2 ? 256 : (cfg == 4 ? 176 : 128));   // weight rows per tile (config 3: 128 x 384, 4: 176 x 384)
   const int ldc = (N + t - 1) / t * t;                       // C rows hold whole tiles
   std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * N * K);
   for (auto& v : A) v = to_op(frand(), op);
@@ -829,6 +829,9 @@ int main(int argc, char** argv) {
   test_gemm_batched(3, EPI_OP, OP_F16, 384, 256, 320, 3, false);
   test_gemm_batched(3, EPI_OP, OP_BF16, 200, 128, 128, 2, false);   // fewer rows than the tile
   test_gemm_batched(3, EPI_F32, OP_F16, 500, 129, 64, 1, true);     // two row tiles, one K step
+  test_gemm_batched(4, EPI_OP, OP_F16, 384, 352, 320, 3, false);    // 176 x 384, compute waves in one column
+  test_gemm_batched(4, EPI_OP, OP_BF16, 300, 176, 128, 2, false);
+  test_gemm_batched(4, EPI_OP, OP_F16, 500, 528, 64, 1, false);     // two row tiles, one K step
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
