@@ -550,6 +550,7 @@ int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (w
 template <typename T>
 int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (weight rows) x 384 (activation rows), 1 x 8 waves
   constexpr size_t lds = 2 * (176 + 384) * 128;
+  if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8>, a, 768, lds, stream);
   if (epi != EPI_OP) return -2;
   return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8>, a, 768, lds, stream);
 }

@@ -256,7 +256,8 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
       return fail(MRA_ENOMEM, std::string("fold weight arena: ") + hipGetErrorString(e));
     }
   }
-  if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);   // A/B runs: 2 = 128 x 128 tiles for P . enc
+  if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);
+  if (const char* env = getenv("MRA_SC_TILE")) h->sc_tile = atoi(env);   // A/B runs: 2 = 128 x 128 tiles for P . enc
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
   for (auto& kv : h->params) {
@@ -511,7 +512,8 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
         sc.W = enc; sc.w_bs = (long long)kv * E;
         sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;
-        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1; sc.tile_cfg = R == 384 ? h->fold_tile : 2;
+        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1;
+        sc.tile_cfg = (R == 384 && h->sc_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
         rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
         if (rc) return chk(rc, "fold scores gemm");
         // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -88,6 +89,7 @@ struct mra_qformer {
   // folded cross-attention (mra_qformer_set_cross_mode): per cross layer the key weight regrouped as [heads][E][64]
   char* arena_f = nullptr;
   bool fold_stale = true;
+  int sc_tile = 5;                                // scores: 5 = the 176 x 384 tile (MRA_SC_TILE=2: 128 x 128)
   int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
   int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
@@ -107,7 +109,8 @@ struct mra_qformer {
 namespace mra_host {
 // folded cross-attention pays once the encoder sequence is long (fewer flops at any Kv, but five launches per layer)
 inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
-inline int fold_kvp(int kv) { return (kv + 127) / 128 * 128; }
+// padded score-row length: whole 128- and 176-row tiles of the scores GEMM, and a multiple of 64 (K of P . enc)
+inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 63) / 64 * 64; }
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);
 }  // namespace mra_host

@@ -832,6 +832,8 @@ int main(int argc, char** argv) {
   test_gemm_batched(4, EPI_OP, OP_F16, 384, 352, 320, 3, false);    // 176 x 384, compute waves in one column
   test_gemm_batched(4, EPI_OP, OP_BF16, 300, 176, 128, 2, false);
   test_gemm_batched(4, EPI_OP, OP_F16, 500, 528, 64, 1, false);     // two row tiles, one K step
+  test_gemm_batched(4, EPI_F32, OP_F16, 384, 300, 192, 2, true);    // scores: ragged N on the 176-row tile
+  test_gemm_batched(4, EPI_F32, OP_F16, 100, 177, 64, 2, true);
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
