@@ -197,11 +197,11 @@ def main():
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
-    fold_pmc = os.path.join(ROOT, "profiles", "r01g_pmc_fold.json")
+    fold_pmc = os.path.join(ROOT, "profiles", "r01i_pmc_fold.json")
     traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
     if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
-        traffic_src = "profiles/r01g_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
+        traffic_src = "profiles/r01i_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
 
     flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
 
@@ -234,8 +234,8 @@ def main():
             },
             "tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
             "roofline": ({"bound": "mfma",
-                          "kernel": "folded cross-attention of one layer, video: per-head Q' GEMM + batched scores GEMM (128x128 tiles, fp32 rows) + "
-                                    "softmax rows + batched P.enc GEMM + per-head context GEMM (5 launches, cross layer 0 of 6)",
+                          "kernel": "folded cross-attention of one layer, video: per-head Q' GEMM + batched scores GEMM (gemm_ws_kernel<176x384>, fp32 rows) + "
+                                    "softmax rows + batched P.enc GEMM (gemm_ws_kernel<176x384>) + per-head context GEMM (5 launches, cross layer 0 of 6)",
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                           "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_alg,
