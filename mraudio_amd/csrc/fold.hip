@@ -80,6 +80,47 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* S, long 
   }
 }
 
+// Second half of the split softmax.  The scores GEMM (EPI_SOFTPART) left P~ = exp2(s - m_tile) per column tile and the
+// tile statistics (m_tile, l_tile) of every row; here one workgroup per row finds m_row = max m_tile,
+// L = sum exp2(m_tile - m_row) l_tile and rescales the row in place by g_tile = exp2(m_tile - m_row) / L.
+// Columns from ntiles * tile_cols to kvp were never written by the GEMM and are zeroed.
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rescale_kernel(T* P, long long ld_p, const float* stat_m, const float* stat_l, int ntiles,
+                                                              int tile_cols, int kvp) {
+  __shared__ float g[128];
+  const int tid = threadIdx.x;
+  const float* sm = stat_m + (long long)blockIdx.x * ntiles;
+  const float* sl = stat_l + (long long)blockIdx.x * ntiles;
+  if (tid < 64) {
+    float m = -3.0e38f;
+    for (int t = tid; t < ntiles; t += 64) m = fmaxf(m, sm[t]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int t = tid; t < ntiles; t += 64) l += __builtin_amdgcn_exp2f(sm[t] - m) * sl[t];
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    for (int t = tid; t < ntiles; t += 64) g[t] = __builtin_amdgcn_exp2f(sm[t] - m) * inv;
+  }
+  __syncthreads();
+  using V8 = typename Vec8<T>::type;
+  T* p = P + (long long)blockIdx.x * ld_p;
+  const int cpt = tile_cols >> 3;   // 16-byte chunks per tile
+  for (int c = tid; c < (kvp >> 3); c += 256) {
+    const int t = c / cpt;
+    V8 v;
+    if (t < ntiles) {
+      v = *reinterpret_cast<const V8*>(p + 8 * c);
+      const float s = g[t];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = from_f32<T>((float)v[e] * s);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
+    }
+    *reinterpret_cast<V8*>(p + 8 * c) = v;
+  }
+}
+
 // dst[b][c][r] = src[b][r][c] for r < R, 0 for R <= r < ld_d; 32 x 32 tiles, grid (ceil(C/32), ceil(ld_d/32), batch)
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_pad_kernel(const T* src, T* dst, int R, int C, int ld_d, long long src_bs,
@@ -146,6 +187,15 @@ int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p,
   if (op_dtype == OP_F16) MRA_SM_T(f16); else MRA_SM_T(bf16);
 #undef MRA_SM_T
 #undef MRA_SM
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_softmax_rescale(void* P, long long ld_p, const float* stat_m, const float* stat_l, int rows, int ntiles, int tile_cols, int kvp,
+                           int op_dtype, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (ntiles <= 0 || ntiles > 128 || (tile_cols & 7) || (kvp & 7) || (ld_p & 7) || ld_p < kvp) return -1;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(softmax_rescale_kernel<f16>, dim3(rows), dim3(256), 0, stream, (f16*)P, ld_p, stat_m, stat_l, ntiles, tile_cols, kvp);
+  else hipLaunchKernelGGL(softmax_rescale_kernel<bf16>, dim3(rows), dim3(256), 0, stream, (bf16*)P, ld_p, stat_m, stat_l, ntiles, tile_cols, kvp);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -56,6 +56,7 @@ __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int
     P.W = (const char*)P.W + b * P.w_bs * 2;
     P.C = (char*)P.C + b * P.c_bs_bytes;
     if (P.bias) P.bias += (long long)b * P.bias_bs;
+    P.batch_row0 = b * P.M;
   }
   constexpr int GM = 8;
   const int per_panel = GM * P.ntiles;
@@ -114,6 +115,51 @@ __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM]
           *reinterpret_cast<typename Vec4<T>::type*>((T*)P.C + coff + n) = o;
         }
       }
+    }
+  }
+}
+
+// EPI_SOFTPART (scores of the folded cross-attention): first half of a softmax split over column tiles.  Needs a wave
+// that holds whole tile rows (one column of compute waves): row m = lane & 15 of fragment j has its TN columns in the
+// four lanes with that lane & 15, so the tile maximum and tile sum of a row are two lane swaps away.
+template <typename T, int FN, int FM>
+__device__ __forceinline__ void epilogue_softpart(const GemmProb& P, f32x4 (&acc)[FN][FM], int n0, int m_base, int tile, int batch_row0,
+                                                  int lane) {
+  const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m_base + j * 16 + lm;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[i][j][e] *= P.alpha;
+        if (n0 + i * 16 + ln + e < P.N) mx = fmaxf(mx, acc[i][j][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+    const bool live = m < P.M;
+    const long long coff = live ? view_off(P.c, m) : 0;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + i * 16 + ln;
+      typename Vec4<T>::type o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = n + e < P.N ? __builtin_amdgcn_exp2f(acc[i][j][e] - mx) : 0.f;
+        o[e] = from_f32<T>(p);
+        l += (float)o[e];          // the sum of what the next GEMM will actually read
+      }
+      if (live) *reinterpret_cast<typename Vec4<T>::type*>((T*)P.C + coff + n) = o;
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (live && ln == 0) {
+      const long long si = ((long long)batch_row0 + m) * P.ntiles + tile;
+      P.stat_m[si] = mx;
+      P.stat_l[si] = l;
     }
   }
 }
@@ -392,7 +438,10 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       }
     }
   }
-  if constexpr (STAGED) {
+  if constexpr (EPI == EPI_SOFTPART) {
+    static_assert(EPI != EPI_SOFTPART || WGN == 1, "the softmax-partial epilogue needs whole tile rows in one wave");
+    epilogue_softpart<T, FN, FM>(P, acc, n0, m0 + wm0, n0 / TN, P.batch_row0, lane);
+  } else if constexpr (STAGED) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
@@ -551,6 +600,7 @@ template <typename T>
 int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (weight rows) x 384 (activation rows), 1 x 8 waves
   constexpr size_t lds = 2 * (176 + 384) * 128;
   if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8>, a, 768, lds, stream);
+  if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8>, a, 768, lds, stream);
   if (epi != EPI_OP) return -2;
   return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8>, a, 768, lds, stream);
 }
@@ -639,6 +689,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 || (p.N % t && !p.n_ragged)) return -1;
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
+    if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;

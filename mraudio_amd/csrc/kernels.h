@@ -15,6 +15,8 @@ enum GemmEpi {
   EPI_RES_F32 = 2,  // C(f32)      = acc + bias + R
   EPI_F32 = 3,      // C(f32)      = acc + bias
   EPI_KV = 4,       // C(op dtype) head-major K/V cache, see GemmProb::kv_*
+  EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile
+                    // sum go to stat_m / stat_l [row][ntiles] (176 x 384 loader-wave tile only: a wave holds whole tile rows)
 };
 
 // Logical activation row m of a "row view" lives at base + (m / rpi) * item_stride + (m % rpi) * ld
@@ -46,11 +48,17 @@ struct GemmProb {
   // n_ragged: N need not be a multiple of the tile; weight rows past N - 1 are read from row N - 1 and their
   // output columns are written anyway, so C rows must hold ceil(N / tile) * tile columns and bias must be null.
   int n_ragged;
+  // EPI_SOFTPART: scale of the scores in log2 units and the per-(row, column tile) statistics, row m of batch entry b at
+  // stat_*[(b * M + m) * ntiles + tile]
+  float alpha;
+  float* stat_m;
+  float* stat_l;
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
                    // rows) loader-wave tile (EPI_OP / EPI_F32 only), 5 = 176 x 384 with the compute waves in one column (EPI_OP only,
                    // N % 176 == 0); the first problem decides
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
+  int batch_row0;  // filled per workgroup: first row of its batch entry in the EPI_SOFTPART statistics
 };
 
 struct GemmArgs {
@@ -133,6 +141,10 @@ int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream);  
 // P[row][0..kv) = softmax(scale * S[row][0..kv)) in the operand dtype, P[row][kv..kvp) = 0
 int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p, int rows, int kv, int kvp, float scale, int op_dtype,
                         hipStream_t stream);
+// second half of the split softmax (first half: EPI_SOFTPART of the scores GEMM): row statistics over the column tiles,
+// then P[row][k] *= exp2(m_tile - m_row) / sum in place; columns [kv_cols, kvp) are zeroed.  tile_cols = columns per tile.
+int launch_softmax_rescale(void* P, long long ld_p, const float* stat_m, const float* stat_l, int rows, int ntiles, int tile_cols, int kvp,
+                           int op_dtype, hipStream_t stream);
 // dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < ld_d; src [batch][R][C], dst [batch][C][ld_d]
 int launch_transpose_pad(const void* src, void* dst, int R, int C, int ld_d, long long src_bs, long long dst_bs, int batch, int op_dtype,
                          hipStream_t stream);

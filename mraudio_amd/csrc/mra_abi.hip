@@ -145,6 +145,7 @@ struct Work {
   char *hA16, *hB16, *qkv16, *ctx16, *qc16, *hC16, *ffn16, *kv16;
   char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
   float* s32;                      // scores [N][R][kvp]
+  float* stat;                     // split softmax: tile maxima [N][R][ntiles], then tile sums
   int nsplit;
   size_t bytes;
 };
@@ -166,12 +167,13 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
   w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = nullptr;
-  w.s32 = nullptr;
+  w.s32 = w.stat = nullptr;
   if (h->ncross > 0 && use_fold(h, Kv)) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
     w.encT = cv.take<char>((size_t)N * E * kvp, 2);
     w.qp16 = cv.take<char>((size_t)N * R * E, 2);
     w.s32 = cv.take<float>((size_t)N * R * kvp);
+    w.stat = cv.take<float>((size_t)2 * N * R * ((Kv + 175) / 176));
     w.p16 = cv.take<char>((size_t)N * R * kvp, 2);
     w.u16 = cv.take<char>((size_t)N * R * E, 2);
   } else {
@@ -257,7 +259,8 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
     }
   }
   if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);
-  if (const char* env = getenv("MRA_SC_TILE")) h->sc_tile = atoi(env);   // A/B runs: 2 = 128 x 128 tiles for P . enc
+  if (const char* env = getenv("MRA_SC_TILE")) h->sc_tile = atoi(env);
+  if (const char* env = getenv("MRA_SPLIT_SOFTMAX")) h->split_softmax = atoi(env) != 0;   // A/B runs: 2 = 128 x 128 tiles for P . enc
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
   for (auto& kv : h->params) {
@@ -507,18 +510,31 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = 1;
         rc = launch_gemm(&d, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold q' gemm");
-        // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, fp32, rows padded to kvp columns
+        // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, rows padded to kvp columns
         GemmProb sc{};
         sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
         sc.W = enc; sc.w_bs = (long long)kv * E;
-        sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;
         sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1;
         sc.tile_cfg = (R == 384 && h->sc_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
-        rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
-        if (rc) return chk(rc, "fold scores gemm");
-        // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
-        rc = launch_softmax_rows(w.s32, kvp, w.p16, kvp, N * R, kv, kvp, 0.125f, op, stream);
-        if (rc) return chk(rc, "fold softmax");
+        if (sc.tile_cfg == 5 && h->split_softmax) {
+          // 6b + 6c fused: the GEMM's epilogue leaves exp2(s - tile maximum) in the operand dtype plus tile statistics;
+          // one pass over P rescales every row by exp2(m_tile - m_row) / sum.  The scores never exist in fp32 in HBM.
+          const int ntiles = (kv + 175) / 176;
+          sc.C = w.p16; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * esz;
+          sc.alpha = 0.125f * 1.4426950408889634f;
+          sc.stat_m = w.stat; sc.stat_l = w.stat + (size_t)N * R * ntiles;
+          rc = launch_gemm(&sc, 1, EPI_SOFTPART, op, stream);
+          if (rc) return chk(rc, "fold scores gemm (softmax partials)");
+          rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);
+          if (rc) return chk(rc, "fold softmax rescale");
+        } else {
+          sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;   // fp32 rows
+          rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
+          if (rc) return chk(rc, "fold scores gemm");
+          // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
+          rc = launch_softmax_rows(w.s32, kvp, w.p16, kvp, N * R, kv, kvp, 0.125f, op, stream);
+          if (rc) return chk(rc, "fold softmax");
+        }
         // 6d. U[n] = P[n] enc[n]: [R, kvp] x [E, kvp]^T per item
         GemmProb pv{};
         pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;

@@ -89,6 +89,7 @@ struct mra_qformer {
   // folded cross-attention (mra_qformer_set_cross_mode): per cross layer the key weight regrouped as [heads][E][64]
   char* arena_f = nullptr;
   bool fold_stale = true;
+  bool split_softmax = true;                      // scores GEMM writes exp2(s - tile max) + tile statistics (MRA_SPLIT_SOFTMAX=0: fp32 rows)
   int sc_tile = 5;                                // scores: 5 = the 176 x 384 tile (MRA_SC_TILE=2: 128 x 128)
   int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
