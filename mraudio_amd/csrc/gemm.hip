@@ -19,6 +19,7 @@
 // remap so that the 32 concurrently running workgroups of one XCD share operand panels in its L2.
 // Other main loops that were tried and measured (ring, prefetch, flag hand-off ...) live in
 // gemm_experiments.inc, outside the shipped library; verdicts in DESIGN.md section 8.
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // (head, query) rows of an item against a 128-row slab of the other operand, so that operand streams once).
 // 176 x 384 with the 8 compute waves in one column (WGM = 8): P . enc of the folded path -- N = 1408 = 8 x 176, so
 // 32 items give exactly 256 workgroups, one per CU, and each streams its 176-row slab of enc^T exactly once.
-template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4>  // NODMA: diagnostic only (wrong results)
+template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4, bool NTW = false>  // NODMA: diagnostic only (wrong results); NTW: non-temporal loads of the weight-side slab
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int BK = 64, ROWB = BK * 2;
   constexpr int WGN = 8 / WGM, WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
@@ -385,7 +386,10 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       const long long koff = (long long)kt * ROWB;
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        if (i * 256 + wq0 < NCHUNK) glds16(src[i] + koff, base + (wq0 + i * 256) * 16);   // wave-uniform: whole 64-chunk pieces
+        if (i * 256 + wq0 < NCHUNK) {   // wave-uniform: whole 64-chunk pieces
+          if (NTW && (i * 256 + wq0) / 8 < TN) glds16_nt(src[i] + koff, base + (wq0 + i * 256) * 16);   // rows [0, TN): read by this workgroup only
+          else glds16(src[i] + koff, base + (wq0 + i * 256) * 16);
+        }
     };
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -599,6 +603,13 @@ int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (w
 template <typename T>
 int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (weight rows) x 384 (activation rows), 1 x 8 waves
   constexpr size_t lds = 2 * (176 + 384) * 128;
+  static const bool nt = getenv("MRA_FOLD_NT") ? atoi(getenv("MRA_FOLD_NT")) != 0 : true;   // A/B switch
+  if (nt) {
+    if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
+    if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8, true>, a, 768, lds, stream);
+    if (epi == EPI_OP) return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true>, a, 768, lds, stream);
+    return -2;
+  }
   if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8>, a, 768, lds, stream);
   if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8>, a, 768, lds, stream);
   if (epi != EPI_OP) return -2;

@@ -53,6 +53,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(MRA_GLB_PTR(gsrc), MRA_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// same with the non-temporal cache policy (aux = 2): for bytes ONE workgroup reads once (MI355X_MICROARCH.md, nt-weights)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(MRA_GLB_PTR(gsrc), MRA_LDS_PTR(lds_wave_base), 16, 0, 2);
+}
+
 template <typename T>
 __device__ __forceinline__ typename Vec8<T>::type lds_read8(const void* p) {
   return *reinterpret_cast<const typename Vec8<T>::type*>(p);
