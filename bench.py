@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold384"],
                     help="cross-attention formulation (auto = folded from Kv >= 2048)")
     ap.add_argument("--item-groups", type=int, default=1, help="item groups of a long-sequence Q-Former on separate streams (1 = off)")
+    ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
     return ap.parse_args()
@@ -104,6 +105,7 @@ def main():
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
     model.kv_first = not args.no_kv_first
     model.item_groups = args.item_groups
+    model.prioritize_heavy = not args.no_priority
     for m in ("video", "audio"):
         getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

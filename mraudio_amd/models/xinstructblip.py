@@ -134,6 +134,7 @@ class XInstructBLIP(nn.Module):
         self.clip_parallel = True
         self.overlap_modalities = overlap_modalities
         self.kv_first = True             # see fuse_score: light modalities wait for the heavy K/V projection
+        self.prioritize_heavy = True     # see fuse_score
         self.item_groups = 1             # see fuse_score: item groups of a long-sequence Q-Former on separate streams (off:
                                          # the host cannot issue G x 250 launches per step fast enough)
         self.roofline_events = None      # bench instrumentation: {modality: [(start, stop) events per item group]}
@@ -270,10 +271,11 @@ class XInstructBLIP(nn.Module):
             qf._kv_done_event = ev
         return ev
 
-    def _side_stream(self, modality: str) -> torch.cuda.Stream:
-        if modality not in self._streams:
-            self._streams[modality] = torch.cuda.Stream(device=self._device)
-        return self._streams[modality]
+    def _side_stream(self, modality: str, high_priority: bool = False) -> torch.cuda.Stream:
+        key = (modality, high_priority)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=self._device, priority=-1 if high_priority else 0)
+        return self._streams[key]
 
     def _sync(self):
         ver = sum(getattr(self, f"{m}_{n}")._version if n == "query_tokens" else sum(p._version for p in getattr(self, f"{m}_{n}").parameters())
@@ -344,6 +346,8 @@ class XInstructBLIP(nn.Module):
         live = [m for m in self.modalities if m in embeds]
         use_streams = self.overlap_modalities and len(live) > 1
         heavy_done = None
+        if use_streams:
+            live.sort(key=lambda m: int(embeds[m].shape[-2]) * int(embeds[m].shape[-1]), reverse=True)
         if use_streams and self.kv_first:
             # The modality with the largest K/V projection goes first and the others start when that GEMM has
             # finished: a chip-filling GEMM gains nothing from sharing CUs with a latency-bound layer chain (it
@@ -356,7 +360,8 @@ class XInstructBLIP(nn.Module):
         for pos, m in enumerate(live):
             qf: QFormer = getattr(self, f"{m}_Qformer")
             idx = None if index is None else index.get(m)
-            side = self._side_stream(m) if use_streams else cur
+            # the modality with the most work is the step's critical path: its launches go first when both streams are ready
+            side = self._side_stream(m, high_priority=self.prioritize_heavy and pos == 0) if use_streams else cur
             if use_streams:
                 side.wait_stream(cur)
                 if heavy_done is not None and pos > 0:

@@ -312,6 +312,12 @@ def test_bf16_operands_run_and_are_close(dev):
     ref = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(2, -1, -1), O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]))[:, :32]
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 2e-2, rel  # bf16 has 8 significand bits: ~8x the f16 error; f16 is the default for that reason
+    for mode in ("fold", "fold384"):           # the folded cross-attention in bf16, both tile families
+        qf.set_cross_mode(mode)
+        got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"].cpu()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert rel < 2e-2, (mode, rel)
+    qf.set_cross_mode("auto")
 
 
 def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, dev):
