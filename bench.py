@@ -307,7 +307,8 @@ def cpu_baseline(args, kv, L):
     threads = host_threads()
     torch.set_num_threads(threads)
     log(f"cpu baseline: {threads} threads")
-    n = args.cpu_clips if args.cpu_clips > 0 else (4 if args.workload == "clip32x32" else 32)
+    # bounded sample: ~0.47 s per 32-frame clip on 16 threads -> 24 clips = ~11 s of CPU work (reference item shape: 0.05 s per item)
+    n = args.cpu_clips if args.cpu_clips > 0 else (24 if args.workload == "clip32x32" else 256)
     cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
     ws = {"video": O.init_weights(cfgs["video"], seed=0), "audio": O.init_weights(cfgs["audio"], seed=1)}
     g = torch.Generator().manual_seed(1234)

@@ -135,7 +135,11 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
  *                 scores kept in fp32;
  *   0  automatic (default): folded from Kv >= 2048.
  *   3  as 2 with the 128 x 384 loader-wave tile instead of the 128 x 128 tiles (A/B runs: no faster).
- * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
+ * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache.
+ * A/B switches of the folded path, read from the environment at mra_qformer_create / first launch (defaults in brackets):
+ *   MRA_SC_TILE [5] / MRA_PV_TILE [5]   2 = plain 128 x 128 tiles for the scores / P.enc GEMM instead of the 176 x 384 tile
+ *   MRA_SPLIT_SOFTMAX [1]               0 = fp32 score rows + softmax_rows kernel instead of the split softmax
+ *   MRA_FOLD_NT [1]                     0 = default cache policy for the once-read operand slab */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
  * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one
