@@ -357,12 +357,14 @@ class XInstructBLIP(nn.Module):
             kv_flops = 2.0 * n_local * embeds[heavy].shape[-2] * embeds[heavy].shape[-1] * 9216
             if kv_flops >= 1e12:                  # ~1 ms of GEMM; below that the wait costs more than the contention
                 heavy_done = self._kv_done_event(heavy)
+        used_streams = []
         for pos, m in enumerate(live):
             qf: QFormer = getattr(self, f"{m}_Qformer")
             idx = None if index is None else index.get(m)
             # the modality with the most work is the step's critical path: its launches go first when both streams are ready
             side = self._side_stream(m, high_priority=self.prioritize_heavy and pos == 0) if use_streams else cur
             if use_streams:
+                used_streams.append(side)
                 side.wait_stream(cur)
                 if heavy_done is not None and pos > 0:
                     side.wait_event(heavy_done)
@@ -386,9 +388,8 @@ class XInstructBLIP(nn.Module):
                     for t in (enc, z, cls, sim, logit, out["full"].get(m), out.get("inputs_llm", {}).get(m), out.get("atts_llm", {}).get(m)):
                         if t is not None:
                             t.record_stream(cur)
-        if use_streams:
-            for m in live:
-                cur.wait_stream(self._side_stream(m))
+        for side in used_streams:          # join exactly the streams that were forked
+            cur.wait_stream(side)
         mods = [m for m in self.modalities if m in out["logit"]]
         if not mods:
             raise MraError("no features for any of the model's modalities")

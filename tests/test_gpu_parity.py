@@ -372,3 +372,25 @@ def test_item_groups_give_identical_results(video, dev):
             for k in ("query", "full", "cls"):
                 assert torch.equal(one[k], many[k]), (mode, G, k)
     qf.set_cross_mode("auto")
+
+
+def test_modality_streams_are_joined_before_fusion(dev):
+    """The modality Q-Formers run on side streams (one of them high priority); fusion and span selection run on the
+    caller's stream and must wait for BOTH.  Two different batches back to back with a long video sequence: a missing
+    join would fuse the second batch's audio logits with the first batch's (stale) video logits."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    model = XInstructBLIP(seed=4, perturb=True, device=dev)
+    g = torch.Generator().manual_seed(9)
+    n, L = 8, 6
+    ids = torch.randint(1000, 30000, (n, L), generator=g).to(dev)
+    tmask = torch.ones(n, L, dtype=torch.long, device=dev)
+    batches = [{"video": torch.randn(n, 2304, 1408, generator=g).to(dev).half(), "audio": torch.randn(n, 64, 768, generator=g).to(dev).half()}
+               for _ in range(2)]
+    model.overlap_modalities = False
+    want = [model.fuse_score(b, ids, tmask, bs=1, num=n)["fused"].clone() for b in batches]
+    assert not torch.allclose(want[0], want[1])
+    model.overlap_modalities = True
+    for _ in range(3):
+        got = [model.fuse_score(b, ids, tmask, bs=1, num=n)["fused"].clone() for b in batches]
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
