@@ -358,6 +358,8 @@ class XInstructBLIP(nn.Module):
             if kv_flops >= 1e12:                  # ~1 ms of GEMM; below that the wait costs more than the contention
                 heavy_done = self._kv_done_event(heavy)
         used_streams = []
+        sharded = ws > 1
+        local: Dict[str, tuple] = {}
         for pos, m in enumerate(live):
             qf: QFormer = getattr(self, f"{m}_Qformer")
             idx = None if index is None else index.get(m)
@@ -374,12 +376,20 @@ class XInstructBLIP(nn.Module):
                 groups = self.item_groups if (int(enc.shape[1]) >= 2048 and n_local >= 2 * self.item_groups) else 1
                 res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True, item_groups=groups,
                                        kv_events=(self.roofline_events or {}).get(m))
-                z = self._gather(res["query"], n)
-                cls = self._gather(res["cls"], n)
+                z, cls = res["query"], res["cls"]
+                if sharded:      # scored after ONE packed all-gather of every modality's rows, below
+                    local[m] = (z, cls)
+                    if want_full:
+                        out["full"][m] = self._gather(res["full"], n)
+                    if use_streams:
+                        for t in (enc, z, cls, out["full"].get(m)):
+                            if t is not None:
+                                t.record_stream(cur)
+                    continue
                 sim, logit = scorer.cosine_scores(z, cls)
                 out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
                 if want_full:
-                    out["full"][m] = self._gather(res["full"], n)
+                    out["full"][m] = res["full"]
                 if want_llm:  # reference :303-306
                     y = qf.llm_proj(z)
                     out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
@@ -390,6 +400,18 @@ class XInstructBLIP(nn.Module):
                             t.record_stream(cur)
         for side in used_streams:          # join exactly the streams that were forked
             cur.wait_stream(side)
+        if sharded and local:
+            # the only exchange of the path: query embeddings and [CLS] vectors of all modalities in one RCCL all-gather
+            mods_l = list(local)
+            gathered = parallel.all_gather_packed([t for m in mods_l for t in local[m]], n, self.process_group)
+            for k, m in enumerate(mods_l):
+                z, cls = gathered[2 * k], gathered[2 * k + 1]
+                sim, logit = scorer.cosine_scores(z, cls)
+                out["z"][m], out["cls"][m], out["sim"][m], out["logit"][m] = z, cls, sim, logit
+                if want_llm:
+                    y = getattr(self, f"{m}_Qformer").llm_proj(z)
+                    out.setdefault("inputs_llm", {})[m] = y.reshape(bs, num, self.num_query_token, -1).view(bs, num * self.num_query_token, -1)
+                    out.setdefault("atts_llm", {})[m] = torch.ones(bs, num * self.num_query_token, dtype=torch.long, device=self._device)
         mods = [m for m in self.modalities if m in out["logit"]]
         if not mods:
             raise MraError("no features for any of the model's modalities")

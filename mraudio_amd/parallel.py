@@ -59,3 +59,23 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     dist.all_gather_into_tensor(buf, padded, group=group)
     parts = [buf[r * mx: r * mx + sizes[r]] for r in range(ws)]
     return torch.cat(parts, dim=0)
+
+
+def all_gather_packed(locals_: List[torch.Tensor], n_total: int, group=None) -> List[torch.Tensor]:
+    """``all_gather_rows`` of several per-item tensors (same leading dimension) with ONE collective: the rows are
+    packed side by side into ``[n_local, sum(widths)]``, gathered, and split back into ``[n_total, ...]`` views.
+    Four latency-bound RCCL calls per step (query embeddings and [CLS] vectors of two modalities) become one."""
+    rank, ws = world(group)
+    if ws == 1:
+        return list(locals_)
+    n_local = locals_[0].shape[0]
+    dtype = locals_[0].dtype
+    flat = [t.reshape(n_local, -1).to(dtype) for t in locals_]
+    widths = [f.shape[1] for f in flat]
+    packed = torch.cat(flat, dim=1) if len(flat) > 1 else flat[0].contiguous()
+    full = all_gather_rows(packed, n_total, group)
+    out, off = [], 0
+    for t, wdt in zip(locals_, widths):
+        out.append(full[:, off: off + wdt].reshape((n_total,) + tuple(t.shape[1:])).to(t.dtype))
+        off += wdt
+    return out
