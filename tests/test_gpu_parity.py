@@ -394,3 +394,20 @@ def test_modality_streams_are_joined_before_fusion(dev):
     for _ in range(3):
         got = [model.fuse_score(b, ids, tmask, bs=1, num=n)["fused"].clone() for b in batches]
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_folded_path_on_a_small_configuration(dev):
+    """Not the reference geometry (4 heads -> 128 (head, query) rows, 2 layers, E = 256): the folded path then runs on its
+    fallback tiles (128 x 128, fp32 score rows + softmax kernel) and must still match the K/V-cache path and the oracle."""
+    qf, cfg = build_qformer(dev, 256, seed=5, hidden=256, heads=4, inter=512, layers=2, llm_hidden=256)
+    ocfg = oracle_cfg(cfg)
+    w = O.init_weights(ocfg, seed=5, perturb=True)
+    ids, tmask, att, feats = make_inputs(ocfg, 5, 7, 333, 2, True)
+    enc = qf.modality_ln(feats.to(dev))
+    qf.set_cross_mode("kv_cache")
+    ref = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    qf.set_cross_mode("fold")
+    got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    assert (got - ref).abs().max().item() < 5e-3
+    h = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(5, -1, -1), O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]))
+    assert (got.cpu() - h[:, :32]).abs().max().item() < Z_ATOL
