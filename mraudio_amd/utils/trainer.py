@@ -107,8 +107,10 @@ class Trainer:
                 emb = getattr(args, "embeds_folder", None)
                 tp = None if emb else AlproVideoTrainProcessor_Stamps(n_frms=n_frms, image_size=224)
                 vp = None if emb else AlproVideoEvalProcessor_Stamps(n_frms=n_frms, image_size=224)
-                train_dataset = MRDataset(args.video_folder, args.train_annotation_file, tp, None, model="X-InstructBLIP", embeds_root=emb)
-                val_dataset = MRDataset(args.video_folder, args.val_annotation_file, vp, None, model="X-InstructBLIP", embeds_root=emb)
+                from ..processors.audio_processors import BeatsAudioProcessor
+                ap_ = None if emb else BeatsAudioProcessor(model_name="iter3", sampling_rate=16000, n_frames=n_frms, is_eval=False, frame_length=512)
+                train_dataset = MRDataset(args.video_folder, args.train_annotation_file, tp, ap_, model="X-InstructBLIP", embeds_root=emb)
+                val_dataset = MRDataset(args.video_folder, args.val_annotation_file, vp, ap_, model="X-InstructBLIP", embeds_root=emb)
         bs, nw = getattr(args, "batch_size", 1), getattr(args, "num_workers", 0)
         self.train_sampler = DistributedSampler(train_dataset, shuffle=True, num_replicas=self.world_size, rank=self.rank)
         val_sampler = DistributedSampler(val_dataset, shuffle=False, num_replicas=self.world_size, rank=self.rank)
