@@ -17,7 +17,9 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
  *   - return 0 on success, a negative MRA_E* code otherwise; mra_last_error() gives the text;
  *   - a handle is bound to the device that was current at create; calls on one handle are not
- *     re-entrant, distinct handles are independent (one per rank / modality);
+ *     re-entrant, distinct handles are independent (one per rank / modality).  One exception: after
+ *     mra_qformer_prepare, several mra_qformer_forward calls of one handle may be in flight on different
+ *     streams (they only read the handle; each needs its own workspace and outputs);
  *   - tensors are dense row-major; matrices of nn.Linear are [out, in] as PyTorch stores them.
  */
 #ifndef MRA_H_
