@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // (head, query) rows of an item against a 128-row slab of the other operand, so that operand streams once).
 // 176 x 384 with the 8 compute waves in one column (WGM = 8): P . enc of the folded path -- N = 1408 = 8 x 176, so
 // 32 items give exactly 256 workgroups, one per CU, and each streams its 176-row slab of enc^T exactly once.
-template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4, bool NTW = false>  // NODMA: diagnostic only (wrong results); NTW: non-temporal loads of the weight-side slab
+template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4, bool NTW = false, bool WKM = false>  // NODMA: diagnostic only (wrong results); NTW: non-temporal loads of the weight-side slab; WKM: K-major W (GemmProb::w_ld)
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int BK = 64, ROWB = BK * 2;
   constexpr int WGN = 8 / WGM, WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
@@ -369,11 +369,17 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     // ------------------------------- loader waves -------------------------------
     const int lt = tid - 512;  // 0..255
     const char* src[NLD];
+    int wrow[NLD];             // WKM: K row of a weight-side chunk inside the tile
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int q = min(lt + i * 256, NCHUNK - 1);   // chunk of the K tile: rows [0, TN) are W, [TN, TN + TM) are A (TN % 16 == 0)
       const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-      if (row < TN) {
+      wrow[i] = 0;
+      if (WKM && q < TN * 8) {
+        // K-major weights: the tile is [64 k][TN n], TN / 8 chunks per k row, no swizzle (fragments come from transposed reads)
+        wrow[i] = q / (TN / 8);
+        src[i] = (const char*)P.W + ((long long)n0 + (q - wrow[i] * (TN / 8)) * 8) * 2;
+      } else if (row < TN) {
         src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
       } else {
         const int m = min(m0 + row - TN, M - 1);
@@ -387,8 +393,14 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
         if (i * 256 + wq0 < NCHUNK) {   // wave-uniform: whole 64-chunk pieces
-          if (NTW && (i * 256 + wq0) / 8 < TN) glds16_nt(src[i] + koff, base + (wq0 + i * 256) * 16);   // rows [0, TN): read by this workgroup only
-          else glds16(src[i] + koff, base + (wq0 + i * 256) * 16);
+          if (WKM && i * 256 + wq0 < TN * 8) {
+            const long long krow = min(kt * BK + wrow[i], P.k_rows - 1);
+            glds16_nt(src[i] + krow * P.w_ld * 2, base + (wq0 + i * 256) * 16);
+          } else if (NTW && (i * 256 + wq0) / 8 < TN) {
+            glds16_nt(src[i] + koff, base + (wq0 + i * 256) * 16);   // rows [0, TN): read by this workgroup only
+          } else {
+            glds16(src[i] + koff, base + (wq0 + i * 256) * 16);
+          }
         }
     };
     stage(0, 0);
@@ -415,6 +427,10 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     const int c = (4 * ks + (lane >> 4)) ^ ((r >> 1) & 7);
     foff[ks] = r * ROWB + c * 16;
   }
+  // WKM: per-lane address inside the [64 k][TN n] weight tile for the transposed reads (row 8 g + (j >> 2), 4 columns from 4 (j & 3))
+  const unsigned wtr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem +
+                       (8 * (lane >> 4) + ((lane & 15) >> 2)) * (TN * 2) + (lane & 3) * 8;
+  static_assert(!WKM || WGN == 1, "K-major weights: one column of compute waves");
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -431,6 +447,30 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       typename Vec8<T>::type b[FM];
 #pragma unroll
       for (int j = 0; j < FM; ++j) b[j] = lds_read8<T>(xb + j * 16 * ROWB + foff[ks]);
+      if constexpr (WKM) {
+        // fragment of weight tile i: lane (column n = 16 i + (lane & 15)) needs k = 32 ks + 8 (lane >> 4) .. + 7 = two
+        // transposed 4 x 16 blocks of the [k][n] tile; the next fragment's reads fly while this one's MFMAs issue
+        constexpr int WP = TN * 2;
+        const unsigned tb = wtr + (kt & 1) * BUF + ks * 32 * WP;
+        i16x4 f[2][2];   // ping-pong fragment registers: indexed by constants after unrolling, so no moves of in-flight data
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(f[0][0]), "=&v"(f[0][1]) : "v"(tb), "n"(4 * WP) : "memory");
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          if (i + 1 < FN) {
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                         : "=&v"(f[(i + 1) & 1][0]), "=&v"(f[(i + 1) & 1][1]) : "v"(tb + (i + 1) * 32), "n"(4 * WP) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[i & 1][0]), "+v"(f[i & 1][1])::"memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[i & 1][0]), "+v"(f[i & 1][1])::"memory");
+          }
+          const i16x4 c0 = f[i & 1][0], c1 = f[i & 1][1];
+          i16x8 v;
+          v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+          const typename Vec8<T>::type a_cur = __builtin_bit_cast(typename Vec8<T>::type, v);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a_cur, b[j], acc[i][j]);
+        }
+      } else {
       typename Vec8<T>::type a_cur = lds_read8<T>(wb + foff[ks]);
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
@@ -439,6 +479,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a_cur, b[j], acc[i][j]);
         a_cur = a_nxt;
+      }
       }
     }
   }
@@ -603,6 +644,10 @@ int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (w
 template <typename T>
 int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (weight rows) x 384 (activation rows), 1 x 8 waves
   constexpr size_t lds = 2 * (176 + 384) * 128;
+  if (a.p[0].w_ld > 0) {   // K-major weights (P . enc straight from the encoder tokens)
+    if (epi != EPI_OP) return -2;
+    return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true>, a, 768, lds, stream);
+  }
   static const bool nt = getenv("MRA_FOLD_NT") ? atoi(getenv("MRA_FOLD_NT")) != 0 : true;   // A/B switch
   if (nt) {
     if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
@@ -701,6 +746,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.K % 64 || (p.N % t && !p.n_ragged)) return -1;
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
+    if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;

@@ -170,7 +170,7 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.s32 = w.stat = nullptr;
   if (h->ncross > 0 && use_fold(h, Kv)) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
-    w.encT = cv.take<char>((size_t)N * E * kvp, 2);
+    if (!fold_kmajor(h)) w.encT = cv.take<char>((size_t)N * E * kvp, 2);
     w.qp16 = cv.take<char>((size_t)N * R * E, 2);
     w.s32 = cv.take<float>((size_t)N * R * kvp);
     w.stat = cv.take<float>((size_t)2 * N * R * ((Kv + 175) / 176));
@@ -260,6 +260,7 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
   }
   if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);
   if (const char* env = getenv("MRA_SC_TILE")) h->sc_tile = atoi(env);
+  if (const char* env = getenv("MRA_PV_KMAJOR")) h->pv_kmajor = atoi(env) != 0;
   if (const char* env = getenv("MRA_SPLIT_SOFTMAX")) h->split_softmax = atoi(env) != 0;   // A/B runs: 2 = 128 x 128 tiles for P . enc
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
@@ -426,8 +427,10 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
   const int R = c.heads * Q, kvp = fold_kvp(kv);
   if (fold) {
     // folded cross-attention: enc^T per item (the K-contiguous operand of P . enc), key weights regrouped per head
-    rc = launch_transpose_pad(enc, w.encT, kv, E, kvp, (long long)kv * E, (long long)E * kvp, N, op, stream);
-    if (rc) return chk(rc, "enc transpose");
+    if (!fold_kmajor(h)) {
+      rc = launch_transpose_pad(enc, w.encT, kv, E, kvp, (long long)kv * E, (long long)E * kvp, N, op, stream);
+      if (rc) return chk(rc, "enc transpose");
+    }
     if ((rc = mra_qformer_prepare(h, stream_))) return rc;
   } else if (h->ncross > 0) {
     // K/V of every cross layer in one GEMM, scattered head-major
@@ -538,7 +541,11 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         // 6d. U[n] = P[n] enc[n]: [R, kvp] x [E, kvp]^T per item
         GemmProb pv{};
         pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
-        pv.W = w.encT; pv.w_bs = (long long)E * kvp;
+        if (fold_kmajor(h)) {   // the encoder tokens themselves: [kv][E] is W K-major; rows kv .. kvp repeat the last token against P = 0
+          pv.W = enc; pv.w_bs = (long long)kv * E; pv.w_ld = E; pv.k_rows = kv;
+        } else {
+          pv.W = w.encT; pv.w_bs = (long long)E * kvp;
+        }
         pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
         pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N;
         pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);

@@ -91,6 +91,7 @@ struct mra_qformer {
   bool fold_stale = true;
   bool split_softmax = true;                      // scores GEMM writes exp2(s - tile max) + tile statistics (MRA_SPLIT_SOFTMAX=0: fp32 rows)
   int sc_tile = 5;                                // scores: 5 = the 176 x 384 tile (MRA_SC_TILE=2: 128 x 128)
+  bool pv_kmajor = true;                          // P . enc reads the encoder tokens themselves (K-major weights, no enc^T copy); MRA_PV_KMAJOR=0
   int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
   int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
@@ -111,6 +112,10 @@ namespace mra_host {
 // folded cross-attention pays once the encoder sequence is long (fewer flops at any Kv, but five launches per layer)
 inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
 // padded score-row length: whole 128- and 176-row tiles of the scores GEMM, and a multiple of 64 (K of P . enc)
+// P . enc on the 176 x 384 tile with K-major weights: no transposed copy of the encoder tokens is needed
+inline bool fold_kmajor(const mra_qformer* h) {
+  return h->pv_kmajor && h->pv_tile == 5 && h->cfg.heads * h->cfg.n_query == 384 && h->cfg.enc_width % 176 == 0;
+}
 inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 63) / 64 * 64; }
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);

@@ -307,6 +307,37 @@ static void test_attention(int op, int items, int heads, int q_rows, int kv_len,
   report(name, worst, op == OP_F16 ? 3e-3 : 2e-2);
 }
 
+// P . enc form: W given K-major ([k_rows][ldw] row-major, columns = output n), K padded beyond k_rows where A is zero
+static void test_gemm_kmajor(int op, int M, int N, int K, int k_rows, int batch) {
+  gemm_force_config(-1);
+  const int ldw = N + 16;
+  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * k_rows * ldw);
+  for (size_t b = 0; b < (size_t)batch; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k) A[(b * M + m) * K + k] = to_op(k < k_rows ? frand() : 0.f, op);
+  for (auto& v : W) v = to_op(frand(0.05f), op);
+  Dev<uint16_t> dA(A), dW(W), dC((size_t)batch * M * N);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.C = dC.p; p.c = RowView{0, M, N};
+  p.M = M; p.N = N; p.K = K; p.batch = batch; p.a_bs = (long long)M * K; p.w_bs = (long long)k_rows * ldw; p.c_bs_bytes = (long long)M * N * 2;
+  p.w_ld = ldw; p.k_rows = k_rows; p.tile_cfg = 5;
+  const int rc = launch_gemm(&p, 1, EPI_OP, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> c = dC.get();
+  double worst = rc ? 1e30 : 0;
+  for (int b = 0; b < batch && !rc; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < k_rows; ++k) acc += (double)from_op(A[((size_t)b * M + m) * K + k], op) * from_op(W[((size_t)b * k_rows + k) * ldw + n], op);
+        worst = std::max(worst, fabs(from_op(c[((size_t)b * M + m) * N + n], op) - acc) / (1 + fabs(acc)));
+      }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm K-major W %s M%d N%d K%d (rows %d) x%d", op == OP_F16 ? "f16" : "bf16", M, N, K, k_rows, batch);
+  report(name, worst, 3e-3);
+}
+
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
   gemm_force_config(-1);
@@ -833,6 +864,9 @@ int main(int argc, char** argv) {
   test_gemm_batched(4, EPI_OP, OP_BF16, 300, 176, 128, 2, false);
   test_gemm_batched(4, EPI_OP, OP_F16, 500, 528, 64, 1, false);     // two row tiles, one K step
   test_gemm_batched(4, EPI_F32, OP_F16, 384, 300, 192, 2, true);    // scores: ragged N on the 176-row tile
+  test_gemm_kmajor(OP_F16, 384, 352, 320, 300, 2);                  // P . enc with the weights K-major (transposed LDS reads)
+  test_gemm_kmajor(OP_F16, 200, 176, 64, 64, 3);
+  test_gemm_kmajor(OP_BF16, 384, 528, 192, 150, 1);
   test_gemm_batched(4, EPI_F32, OP_F16, 100, 177, 64, 2, true);
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
