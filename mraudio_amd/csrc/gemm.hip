@@ -454,11 +454,12 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
         const unsigned tb = wtr + (kt & 1) * BUF + ks * 32 * WP;
         i16x4 f[2][2];   // ping-pong fragment registers: indexed by constants after unrolling, so no moves of in-flight data
         asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(f[0][0]), "=&v"(f[0][1]) : "v"(tb), "n"(4 * WP) : "memory");
+        static_assert(FN * 32 + 4 * WP < 65536, "fragment offsets must fit the ds_read offset field");
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
           if (i + 1 < FN) {
-            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                         : "=&v"(f[(i + 1) & 1][0]), "=&v"(f[(i + 1) & 1][1]) : "v"(tb + (i + 1) * 32), "n"(4 * WP) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                         : "=&v"(f[(i + 1) & 1][0]), "=&v"(f[(i + 1) & 1][1]) : "v"(tb), "n"((i + 1) * 32), "n"((i + 1) * 32 + 4 * WP) : "memory");
             asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[i & 1][0]), "+v"(f[i & 1][1])::"memory");
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[i & 1][0]), "+v"(f[i & 1][1])::"memory");
