@@ -199,11 +199,11 @@ def main():
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
-    fold_pmc = os.path.join(ROOT, "profiles", "r01k_pmc_fold.json")
+    fold_pmc = os.path.join(ROOT, "profiles", "r01o_pmc_fold.json")
     traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
     if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
-        traffic_src = "profiles/r01k_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
+        traffic_src = "profiles/r01o_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
 
     flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
 
