@@ -172,7 +172,8 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
     if (!fold_kmajor(h)) w.encT = cv.take<char>((size_t)N * E * kvp, 2);
     w.qp16 = cv.take<char>((size_t)N * R * E, 2);
-    w.s32 = cv.take<float>((size_t)N * R * kvp);
+    const bool split = R == 384 && h->sc_tile == 5 && h->split_softmax;   // then the scores never exist in fp32
+    if (!split) w.s32 = cv.take<float>((size_t)N * R * kvp);
     w.stat = cv.take<float>((size_t)2 * N * R * ((Kv + 175) / 176));
     w.p16 = cv.take<char>((size_t)N * R * kvp, 2);
     w.u16 = cv.take<char>((size_t)N * R * E, 2);
