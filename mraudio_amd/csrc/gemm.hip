@@ -18,7 +18,7 @@
 // LDS as whole 128-byte lines.  Workgroups walk tiles in 8-row-tile panels after an XCD-contiguous
 // remap so that the 32 concurrently running workgroups of one XCD share operand panels in its L2.
 // Other main loops that were tried and measured (ring, prefetch, flag hand-off ...) live in
-// gemm_experiments.inc, outside the shipped library; verdicts in DESIGN.md section 8.
+// tests/native/gemm_experiments.inc, outside the product tree and the shipped library; verdicts in DESIGN.md section 8.
 #include <cstdlib>
 #include <mutex>
 #include <set>

@@ -55,6 +55,7 @@ def main(argv=None) -> None:
     ap.add_argument("--model", default="X-InstructBLIP")
     ap.add_argument("--model-path", default=None)
     ap.add_argument("--audio-encoder", default=None)
+    ap.add_argument("--checkpoint", default=None, help="state dict (.pth, reference key names) with the Q-Former / LN / projection weights")
     ap.add_argument("--video-folder", default=None)
     ap.add_argument("--annotation-file", default=None)
     ap.add_argument("--embeds-folder", default=None, help="pre-extracted encoder outputs, <vid>.pt")
@@ -66,7 +67,8 @@ def main(argv=None) -> None:
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N seeded synthetic videos instead of a corpus")
     args = ap.parse_args(argv)
     n_frms = 60 if args.dataset == "QVH" else 20
-    model = XInstructBLIP(args.model_path, args.audio_encoder, device=args.device)
+    model = XInstructBLIP(args.model_path, args.audio_encoder, device=args.device, checkpoint=args.checkpoint)
+    print(f"weights: {model.weights_source}")
     if args.synthetic:
         ds = SyntheticMRDataset(args.synthetic, T=n_frms)
     else:

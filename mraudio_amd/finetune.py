@@ -46,6 +46,7 @@ def main(argv=None):
     ap.add_argument("--model", default="X-InstructBLIP")
     ap.add_argument("--model-path", default=None)
     ap.add_argument("--audio-encoder", default=None)
+    ap.add_argument("--checkpoint", default=None, help="initial weights: state dict (.pth, reference key names)")
     ap.add_argument("--video-folder", default=None)
     ap.add_argument("--train-annotation-file", default=None)
     ap.add_argument("--val-annotation-file", default=None)

@@ -69,6 +69,62 @@ class EvaViTg(nn.Module):
             x = blk(x)
         return x
 
+    # ---- weights ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def init_seeded_(self, seed: int = 0) -> "EvaViTg":
+        """Seeded synthetic weights (no EVA checkpoint exists offline), drawn on the CPU in ``state_dict()`` order from one
+        generator so every machine derives the same tensors: matrices / embeddings N(0, 0.02), biases N(0, 0.02),
+        LayerNorm gains 1 + N(0, 0.1), LayerNorm biases N(0, 0.05) -- every parameter influences the output."""
+        g = torch.Generator().manual_seed(seed)
+        for k, p in self.state_dict().items():
+            if "norm" in k:
+                v = (1.0 + torch.randn(p.shape, generator=g) * 0.1) if k.endswith("weight") else torch.randn(p.shape, generator=g) * 0.05
+            else:
+                v = torch.randn(p.shape, generator=g) * 0.02
+            p.copy_(v.to(p.dtype))
+        return self
+
+    def hf_state_dict(self) -> dict:
+        """This module's weights under the key names of ``transformers.InstructBlipVisionModel`` (the in-image structural
+        stand-in for LAVIS' EVA ViT-g, SURVEY 8c).  Name map::
+
+            cls_token                      embeddings.class_embedding            [1, 1, D]
+            pos_embed                      embeddings.position_embedding         [1, 257, D]
+            patch_embed.{weight,bias}      embeddings.patch_embedding.{weight,bias}
+            blocks.i.norm1 / norm2         encoder.layers.i.layer_norm1 / layer_norm2
+            blocks.i.attn.qkv.weight       encoder.layers.i.self_attn.qkv.weight [3D, D]
+            blocks.i.attn.{q,v}_bias       encoder.layers.i.self_attn.qkv.bias = cat(q_bias, 0, v_bias)   (no key bias)
+            blocks.i.attn.proj             encoder.layers.i.self_attn.projection
+            blocks.i.fc1 / fc2             encoder.layers.i.mlp.fc1 / fc2
+            (none)                         post_layernorm   -- the reference's separate ``video_ln`` plays that role
+        """
+        sd = {"embeddings.class_embedding": self.cls_token, "embeddings.position_embedding": self.pos_embed,
+              "embeddings.patch_embedding.weight": self.patch_embed.weight, "embeddings.patch_embedding.bias": self.patch_embed.bias}
+        for i, b in enumerate(self.blocks):
+            p = f"encoder.layers.{i}."
+            sd[p + "self_attn.qkv.weight"] = b.attn.qkv.weight
+            sd[p + "self_attn.qkv.bias"] = torch.cat((b.attn.q_bias, torch.zeros_like(b.attn.v_bias), b.attn.v_bias))
+            for a, c in (("self_attn.projection", b.attn.proj), ("layer_norm1", b.norm1), ("layer_norm2", b.norm2), ("mlp.fc1", b.fc1), ("mlp.fc2", b.fc2)):
+                sd[p + a + ".weight"], sd[p + a + ".bias"] = c.weight, c.bias
+        return {k: v.detach() for k, v in sd.items()}
+
+    @torch.no_grad()
+    def load_hf_state_dict(self, sd: dict) -> None:
+        """Inverse of ``hf_state_dict``: accepts an ``InstructBlipVisionModel`` state dict (``post_layernorm.*`` is skipped: it
+        belongs to ``video_ln``).  The HF key-bias slice must be zero, as EVA has no key bias."""
+        D = self.num_features
+        self.cls_token.copy_(sd["embeddings.class_embedding"]); self.pos_embed.copy_(sd["embeddings.position_embedding"])
+        self.patch_embed.weight.copy_(sd["embeddings.patch_embedding.weight"]); self.patch_embed.bias.copy_(sd["embeddings.patch_embedding.bias"])
+        for i, b in enumerate(self.blocks):
+            p = f"encoder.layers.{i}."
+            b.attn.qkv.weight.copy_(sd[p + "self_attn.qkv.weight"])
+            bias = sd[p + "self_attn.qkv.bias"]
+            if bool(bias[D:2 * D].abs().max() > 0):
+                raise ValueError(f"layer {i}: non-zero key bias cannot be represented (EVA ViT-g has q / v bias only)")
+            b.attn.q_bias.copy_(bias[:D]); b.attn.v_bias.copy_(bias[2 * D:])
+            for a, c in (("self_attn.projection", b.attn.proj), ("layer_norm1", b.norm1), ("layer_norm2", b.norm2), ("mlp.fc1", b.fc1), ("mlp.fc2", b.fc2)):
+                c.weight.copy_(sd[p + a + ".weight"]); c.bias.copy_(sd[p + a + ".bias"])
+
     def flops_per_frame(self) -> float:
         n, d = self.pos_embed.shape[1], self.num_features
         mlp = self.blocks[0].fc1.out_features

@@ -117,7 +117,7 @@ class XInstructBLIP(nn.Module):
                  perturb: bool = False, op_dtype: torch.dtype = torch.float16, device=None,
                  compat_repeat: bool = True, score_alpha: float = 0.5, fuse_weights: Optional[Sequence[float]] = None,
                  process_group=None, qformer_overrides: Optional[dict] = None, overlap_modalities: bool = True,
-                 llm_hidden_size: int = 4096):
+                 llm_hidden_size: int = 4096, checkpoint: Optional[str] = None):
         super().__init__()
         self.model_path, self.audio_path = model_path, audio_path
         self.modalities = list(modalities) if modalities is not None else ["audio", "video"]  # reference :71
@@ -135,9 +135,8 @@ class XInstructBLIP(nn.Module):
         self.overlap_modalities = overlap_modalities
         self.kv_first = True             # see fuse_score: light modalities wait for the heavy K/V projection
         self.prioritize_heavy = True     # see fuse_score
-        self.item_groups = 1             # see fuse_score: item groups of a long-sequence Q-Former on separate streams (off:
-                                         # the host cannot issue G x 250 launches per step fast enough)
-        self.roofline_events = None      # bench instrumentation: {modality: [(start, stop) events per item group]}
+        self.encode_chunk = 64           # frames per encoder call of the batched [B*T] encode (row A1)
+        self.roofline_events = None      # bench instrumentation: {modality: (start, stop) events}
         self._streams: Dict[str, torch.cuda.Stream] = {}
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.tokenizer = tokenizer if tokenizer is not None else self.init_tokenizer(truncation_side="left")
@@ -171,6 +170,16 @@ class XInstructBLIP(nn.Module):
                 proj.bias.data.copy_(draw_seeded(mg, (self.llm_hidden_size,), "b", perturb))
         self.to(self._device)
         self._extras_dirty = True
+        # Where the Q-Former / LN / projection weights come from.  The reference downloads them in its constructor
+        # (``:79-194``; ``model_path`` there is the Vicuna directory, ``audio_path`` the BEATs checkpoint); offline they
+        # come from ``checkpoint`` (a state dict with the reference's key names) or stay the seeded synthetic init.
+        self.weights_source = f"synthetic (seed {seed})"
+        if checkpoint is not None:
+            self.load_checkpoint(checkpoint)
+        elif model_path is not None or audio_path is not None:
+            logging.warning("XInstructBLIP(model_path=%r, audio_path=%r): no checkpoint was given, the Q-Former / LayerNorm / "
+                            "projection weights are the SYNTHETIC seeded init -- predictions are not meaningful.  Pass "
+                            "checkpoint=<state dict .pth> (evaluate.py / finetune.py: --checkpoint).", model_path, audio_path)
 
     # ---- construction helpers with the reference's names (:609-735) --------------------------------
     @classmethod
@@ -237,9 +246,23 @@ class XInstructBLIP(nn.Module):
             raise RuntimeError(f"Error(s) in loading state_dict for XInstructBLIP: missing {missing}, unexpected {unexpected}")
         return _IncompatibleKeys(missing, unexpected)
 
-    def load_checkpoint(self, filename, **kwargs):
+    def load_checkpoint(self, filename, strict: bool = False, **kwargs):
+        """Weights-only load of a ``.pth`` holding the reference's key names (``{m}_Qformer.*``, ``{m}_query_tokens``,
+        ``{m}_ln.*``, ``{m}_llm_proj.*``; optionally under ``"model"``).  Not strict by default, like the reference's
+        own loader (``:759-816`` returns the incompatible keys); raises when NOTHING in the file matched."""
         ckpt = torch.load(filename, map_location="cpu", weights_only=True)
-        return self.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=True)
+        sd = ckpt["model"] if "model" in ckpt else ckpt
+        msg = self.load_state_dict(sd, strict=strict)
+        mine = [k for k in sd if k.startswith(tuple(f"{m}_" for m in self.modalities))]
+        if not mine:
+            raise RuntimeError(f"{filename}: no key of this model's modalities {self.modalities} found")
+        self.weights_source = f"checkpoint {filename}"
+        if msg.missing_keys:
+            logging.warning("%s: %d parameters keep their previous values (first: %s)", filename, len(msg.missing_keys), msg.missing_keys[:3])
+        if isinstance(self.tokenizer, HashTokenizer):
+            logging.warning("checkpoint weights are used with the offline HashTokenizer: token ids do NOT match the "
+                            "bert-base-uncased vocabulary the checkpoint was trained with")
+        return msg
 
     def get_optimizer_params(self, weight_decay, lr_scale=1):
         """LAVIS ``BaseModel.get_optimizer_params`` semantics (reference ``:818-820``): parameters that
@@ -295,31 +318,40 @@ class XInstructBLIP(nn.Module):
         self._extras_dirty = False
 
     # ---- the hot path -------------------------------------------------------------------------------------
-    def _encode(self, samples, modality: str):
-        """Row A1: per-position encoder calls (reference ``:262-275``).  Returns
-        (raw [src_items, Kv, E] encoder outputs, index or None, bs, num): item k of the sample-major
-        order the reference builds with ``cat(embeds)[indices]`` (``:281-285``) is ``raw[index[k]]``."""
+    def _encode(self, samples, modality: str, lo: Optional[int] = None, hi: Optional[int] = None):
+        """Row A1: the encoder calls of the reference's per-position loop (``:262-275``: ``T`` sequential
+        calls at batch ``B``), collapsed to ONE sample-major ``[B*T]`` batch fed to the encoder in chunks of
+        ``encode_chunk`` frames.  Item ``k = r * T + i`` of the order the reference builds afterwards with
+        ``cat(embeds)[indices]`` (``:281-285``) is frame ``i`` of sample ``r``, so no gather index is needed:
+        the modality LayerNorm consumes the encoder output in place.  ``[lo, hi)`` restricts the work to one
+        rank's contiguous block of items (clip-sharded inference): the encoder -- 100x the Q-Former's cost --
+        is sharded too, not replicated.  Returns ``(raw [hi - lo, Kv, E], None, bs, num)``."""
         key = f"{modality}_embeds"
         if key in samples:  # pre-computed encoder outputs, already sample-major [B, T, Kv, E]
-            e = samples[key].to(self._device)
+            e = samples[key]
             bs, num = int(e.shape[0]), int(e.shape[1])
-            return e.reshape(bs * num, e.shape[2], e.shape[3]), None, bs, num
+            e = e.reshape(bs * num, e.shape[2], e.shape[3])
+            if lo is not None:
+                e = e[lo:hi]
+            return e.to(self._device), None, bs, num
         encoder = getattr(self, f"{modality}_encoder")
         if encoder is None:
             raise MraError(f"no {modality}_encoder was given and samples has no '{key}'")
-        data = samples[modality].to(self._device)
-        frames = []
+        data = samples[modality]
+        if modality == "video":      # [B, 3, T, H, W] -> sample-major frames [B*T, 3, H, W]
+            bs, num = int(data.shape[0]), int(data.shape[2])
+            frames = data.permute(0, 2, 1, 3, 4).reshape(bs * num, data.shape[1], data.shape[3], data.shape[4])
+        else:                        # [B, T, F, 128] -> [B*T, F, 128]
+            bs, num = int(data.shape[0]), int(data.shape[1])
+            frames = data.reshape(bs * num, data.shape[2], data.shape[3])
+        if lo is not None:
+            frames = frames[lo:hi]
+        outs = []
         with torch.no_grad():
-            if modality == "video":
-                for j in range(data.size(2)):
-                    frames.append(encoder(data[:, :, j, :, :]))
-            else:
-                for j in range(data.size(1)):
-                    frames.append(encoder(data[:, j, :, :]))
-        num, bs = len(frames), int(frames[0].shape[0])
-        raw = torch.cat(frames)  # frame-major [num*bs, Kv, E]
-        index = torch.tensor([i * bs + r for r in range(bs) for i in range(num)], dtype=torch.int64, device=raw.device)
-        return raw, index, bs, num
+            for c0 in range(0, int(frames.shape[0]), max(1, int(self.encode_chunk))):
+                outs.append(encoder(frames[c0: c0 + self.encode_chunk].to(self._device)))
+        raw = outs[0] if len(outs) == 1 else torch.cat(outs)
+        return raw, None, bs, num
 
     @torch.no_grad()
     def fuse_score(self, embeds: Dict[str, torch.Tensor], input_ids: torch.Tensor, text_mask: torch.Tensor, bs: int, num: int,
@@ -372,9 +404,7 @@ class XInstructBLIP(nn.Module):
                     side.wait_event(heavy_done)
             with torch.cuda.stream(side):
                 enc = qf.modality_ln(embeds[m].to(self._device), item_index=idx, items=n_local)
-                # long sequences (folded cross-attention): independent item groups on the Q-Former's group streams
-                groups = self.item_groups if (int(enc.shape[1]) >= 2048 and n_local >= 2 * self.item_groups) else 1
-                res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True, item_groups=groups,
+                res = qf.forward_fused(ids, att, enc, want_query=True, want_full=want_full, want_cls=True,
                                        kv_events=(self.roofline_events or {}).get(m))
                 z, cls = res["query"], res["cls"]
                 if sharded:      # scored after ONE packed all-gather of every modality's rows, below
@@ -437,12 +467,10 @@ class XInstructBLIP(nn.Module):
         for m in self.modalities:
             if m not in samples and f"{m}_embeds" not in samples:
                 continue
-            raw, idx, bs, num = self._encode(samples, m)
-            lo, hi = parallel.shard_range(bs * num, rank, ws)
-            if idx is None:
-                embeds[m] = raw[lo:hi]
-            else:
-                embeds[m], index[m] = raw, idx[lo:hi]
+            src = samples.get(f"{m}_embeds", samples.get(m))
+            n_items = int(src.shape[0]) * int(src.shape[2] if (m == "video" and f"{m}_embeds" not in samples) else src.shape[1])
+            lo, hi = parallel.shard_range(n_items, rank, ws)
+            embeds[m], _, bs, num = self._encode(samples, m, lo, hi)     # this rank's block only: the encoder is sharded too
         if bs is None:
             raise MraError("samples holds none of the model's modalities")
         if self.compat_repeat:   # reference :287-288  ids.repeat(num, 1): row k carries prompt k % bs
@@ -517,15 +545,28 @@ class XInstructBLIP(nn.Module):
         embeds, mask, targets = self.prompt_assembler.assemble_forward(samples, inputs_llm, atts_llm)
         return {"loss": self.llm_model(inputs_embeds=embeds, attention_mask=mask, return_dict=True, labels=targets).loss}
 
+    _WINDOW = re.compile(r"\[\s*(-?\d+(?:\.\d+)?)\s*,\s*(-?\d+(?:\.\d+)?)\s*\]")
+
+    @classmethod
+    def parse_windows(cls, txt: str) -> List[List[float]]:
+        """``text_output`` of the reference's datasets (``utils/mr_dataset.py:100-106``): ``"[[s, e]]"`` or several
+        windows ``"[[s0, e0], [s1, e1]]"`` (QVHighlights), integer or float seconds (``save_float=True`` in the
+        reference's preprocessing).  Returns every ``[start, end]`` pair; ``[[-1, -1]]`` (no window) gives ``[]``.
+        Raises on text with no window at all, so a malformed annotation cannot silently train on an empty target."""
+        wins = [[float(a), float(b)] for a, b in cls._WINDOW.findall(txt)]
+        if not wins:
+            raise ValueError(f"text_output holds no [start, end] window: {txt!r}")
+        return [[min(a, b), max(a, b)] for a, b in wins if a >= 0 and b >= 0]
+
     def _targets(self, samples, bs, num):
-        """Clip-membership targets of the spans in ``samples["text_output"]`` (``"[[s, e]]"`` seconds)."""
+        """Clip-membership targets: position ``i`` of sample ``r`` is positive when its timestamp lies inside ANY of
+        the windows of ``samples["text_output"][r]`` (union over windows, float seconds honoured)."""
         target = torch.zeros(bs, num, dtype=torch.float32, device=self._device)
         ts = samples.get("timestamps") or [list(range(num))] * bs
         for r, txt in enumerate(samples.get("text_output", ["[[-1, -1]]"] * bs)):
-            nums = [int(x) for x in re.findall(r"-?\d+", txt)][:2]
-            if len(nums) == 2 and nums[0] >= 0:
-                t = torch.as_tensor(ts[r], dtype=torch.float32, device=self._device)
-                target[r] = ((t >= nums[0]) & (t <= nums[1])).float()
+            t = torch.as_tensor(ts[r], dtype=torch.float32, device=self._device)
+            for s0, e0 in self.parse_windows(txt):
+                target[r] = torch.maximum(target[r], ((t >= s0) & (t <= e0)).float())
         return target
 
     def enable_qformer_training(self) -> None:

@@ -289,14 +289,11 @@ class QFormer(nn.Module):
 
     def forward_fused(self, input_ids: Optional[torch.Tensor], attention_mask: Optional[torch.Tensor], enc: torch.Tensor,
                       query_embeds: Optional[torch.Tensor] = None, want_query: bool = True, want_full: bool = False,
-                      want_cls: bool = False, item_groups: int = 1, kv_events=None) -> Dict[str, torch.Tensor]:
+                      want_cls: bool = False, kv_events=None) -> Dict[str, torch.Tensor]:
         """A4 on the extension.  enc [N, Kv, E] in the operand dtype (``modality_ln`` output).
         Returns a dict with ``query`` [N,32,H], ``full`` [N,32+L,H], ``cls`` [N,H] (fp32) as requested.
-
-        ``item_groups`` > 1 runs contiguous blocks of items as independent forwards of the same handle on the
-        module's group streams (items never interact): one group's launch tails and dependency gaps are filled by the
-        others'.  ``kv_events``: optional (start, stop) ``torch.cuda.Event`` pair per group for
-        ``mra_qformer_set_kv_events`` (bench instrumentation)."""
+        ``kv_events``: optional (start, stop) ``torch.cuda.Event`` pair for ``mra_qformer_set_kv_events`` (bench
+        instrumentation of the dominant kernel, recorded by the library on the launch stream)."""
         self.sync_weights()
         cfg = self.cfg
         if enc.dim() != 3 or enc.shape[-1] != cfg.enc_width:
@@ -331,50 +328,21 @@ class QFormer(nn.Module):
             out["full"] = torch.empty(N, cfg.n_query + L, cfg.hidden, dtype=torch.float32, device=dev)
         if want_cls:
             out["cls"] = torch.empty(N, cfg.hidden, dtype=torch.float32, device=dev)
-        G = max(1, min(int(item_groups), N))
-        if q_items not in (0, 1):
-            G = 1                                   # per-item query embeddings: keep the single launch sequence
-        bounds = [(N * k) // G for k in range(G + 1)]
         with torch.cuda.device(self._device):
-            sizes = [(int(lib().mra_qformer_workspace_bytes(self._handle, bounds[k + 1] - bounds[k], L, Kv)) + 255) // 256 * 256 for k in range(G)]
-            ws = self._workspace(sum(sizes))
-            cur = torch.cuda.current_stream(self._device)
-            if G > 1:
-                check(lib().mra_qformer_prepare(self._handle, current_stream()), "mra_qformer_prepare")
-            off = 0
-            for k in range(G):
-                lo, n_k = bounds[k], bounds[k + 1] - bounds[k]
-                stream = cur
-                if G > 1:
-                    stream = self._group_stream(k)
-                    stream.wait_stream(cur)
-                if kv_events is not None:
-                    e0, e1 = kv_events[k] if k < len(kv_events) else (None, None)
-                    check(lib().mra_qformer_set_kv_events(self._handle, e0.cuda_event if e0 is not None else None,
-                                                          e1.cuda_event if e1 is not None else None), "set_kv_events")
-
-                def at(t, row_elems, esz):          # raw pointer of item `lo` inside a [N, ...] tensor
-                    return None if t is None else C.c_void_p(t.data_ptr() + lo * row_elems * esz)
-
-                H, S = cfg.hidden, cfg.n_query + L
-                check(lib().mra_qformer_forward(
-                    self._handle, at(input_ids, L, 8), at(attention_mask, S, 8), ptr(query_embeds), q_items,
-                    at(enc, Kv * cfg.enc_width, enc.element_size()), n_k, L, Kv, at(out.get("query"), cfg.n_query * H, 4),
-                    at(out.get("full"), S * H, 4), at(out.get("cls"), H, 4), C.c_void_p(ws.data_ptr() + off), sizes[k],
-                    C.c_void_p(stream.cuda_stream)), "mra_qformer_forward")
-                off += sizes[k]
-            if G > 1:
-                for k in range(G):
-                    cur.wait_stream(self._group_stream(k))
+            nbytes = (int(lib().mra_qformer_workspace_bytes(self._handle, N, L, Kv)) + 255) // 256 * 256
+            ws = self._workspace(nbytes)
             if kv_events is not None:
-                check(lib().mra_qformer_set_kv_events(self._handle, None, None), "set_kv_events")
+                e0, e1 = kv_events
+                check(lib().mra_qformer_set_kv_events(self._handle, e0.cuda_event, e1.cuda_event), "set_kv_events")
+            try:
+                check(lib().mra_qformer_forward(
+                    self._handle, ptr(input_ids), ptr(attention_mask), ptr(query_embeds), q_items, ptr(enc), N, L, Kv,
+                    ptr(out.get("query")), ptr(out.get("full")), ptr(out.get("cls")), ptr(ws), nbytes, current_stream()),
+                    "mra_qformer_forward")
+            finally:
+                if kv_events is not None:
+                    check(lib().mra_qformer_set_kv_events(self._handle, None, None), "set_kv_events")
         return out
-
-    def _group_stream(self, k: int) -> "torch.cuda.Stream":
-        streams = self.__dict__.setdefault("_group_streams", [])
-        while len(streams) <= k:
-            streams.append(torch.cuda.Stream(device=self._device))
-        return streams[k]
 
     def llm_proj(self, z: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """A5: ``{modality}_llm_proj(last_hidden_state[:, :32, :])`` (reference ``:303``)."""

@@ -21,10 +21,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _setup(dev, enc_width, seed):
+def _setup(dev, enc_width, seed, op_dtype=torch.float16):
     from mraudio_amd.qformer import QFormer, QFormerConfig, draw_seeded
 
-    cfg = QFormerConfig(enc_width=enc_width)
+    cfg = QFormerConfig(enc_width=enc_width, op_dtype=op_dtype)
     qf = QFormer(cfg, device=dev)
     g = qf.init_seeded_(seed=seed, perturb=True)
     qt = draw_seeded(g, (1, cfg.n_query, cfg.hidden), "w", True)
@@ -36,11 +36,17 @@ def _setup(dev, enc_width, seed):
     return qf, cfg, ocfg, w
 
 
-def test_forward_backward_matches_oracle_autograd(dev):
-    qf, cfg, ocfg, w = _setup(dev, 1408, 0)
+# (operand dtype, forward |d| bar, relative-Frobenius bar per gradient tensor, peak-error bar).  bf16 is BASELINE config 5's
+# stated dtype: 8 significand bits instead of f16's 11, so every bar is 8x the f16 one (the measured errors scale the same way)
+DTYPES = [(torch.float16, 1e-2, 2e-2, 5e-2), (torch.bfloat16, 8e-2, 1.6e-1, 4e-1)]
+
+
+@pytest.mark.parametrize("op_dtype,fwd_tol,rel_tol,peak_tol", DTYPES, ids=["f16", "bf16"])
+def test_forward_backward_matches_oracle_autograd(dev, op_dtype, fwd_tol, rel_tol, peak_tol):
+    qf, cfg, ocfg, w = _setup(dev, 1408, 0, op_dtype)
     n, L, kv = 4, 9, 40
     ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 77, True)
-    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).half()   # the exact operand the kernels see
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).to(op_dtype)   # the exact operand the kernels see
     g = torch.Generator().manual_seed(5)
     rq, rc = torch.randn(n, 32, 768, generator=g), torch.randn(n, 768, generator=g)
 
@@ -52,10 +58,10 @@ def test_forward_backward_matches_oracle_autograd(dev):
 
     # HIP path
     q, c = qf.forward_train(ids.to(dev), att.to(dev), enc.to(dev))
-    assert (q.cpu() - h[:, :32].detach()).abs().max().item() < 1e-2
-    assert (c.cpu() - h[:, 32].detach()).abs().max().item() < 1e-2
+    assert (q.cpu() - h[:, :32].detach()).abs().max().item() < fwd_tol
+    assert (c.cpu() - h[:, 32].detach()).abs().max().item() < fwd_tol
     inf = qf.forward_fused(ids.to(dev), att.to(dev), enc.to(dev), want_query=True, want_cls=True)
-    assert (inf["query"] - q).abs().max().item() < 1e-2          # training keeps the pre-GELU value in f16 (one more rounding)
+    assert (inf["query"] - q).abs().max().item() < fwd_tol          # training keeps the pre-GELU value in f16 (one more rounding)
     loss = (q * rq.to(dev)).sum() + (c * rc.to(dev)).sum()
     loss.backward()
     torch.cuda.synchronize()
@@ -73,14 +79,14 @@ def test_forward_backward_matches_oracle_autograd(dev):
             # softmax is invariant to a per-query shift of the scores, so the true key-bias gradient is 0 (the
             # oracle's value is fp32 noise): the kernel's must be noise too, measured against the query-bias one
             scale = wl[k.replace(".key.", ".query.")].grad.norm().item()
-            assert got.norm().item() < 2e-2 * scale + 1e-4, (k, got.norm().item(), scale)
+            assert got.norm().item() < rel_tol * scale + 1e-4, (k, got.norm().item(), scale)
             continue
         rel = ((got - gref).norm() / denom).item()
         peak = (got - gref).abs().max().item() / gref.abs().max().item()
         if rel > worst:
             worst, worst_name = rel, k
-        assert rel < 2e-2 and peak < 5e-2, (k, rel, peak)
-    print("worst relative gradient error", worst, worst_name)
+        assert rel < rel_tol and peak < peak_tol, (k, rel, peak)
+    print("worst relative gradient error", op_dtype, worst, worst_name)
     # parameter .grad fields are views of the flat buffer
     p = qf.bert.encoder.layer[3].attention.output.dense.weight
     assert p.grad is not None and p.grad.data_ptr() == qf.grad_of("bert.encoder.layer.3.attention.output.dense.weight").data_ptr()

@@ -324,7 +324,7 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
     """The folded cross-attention (S = (Q W_k) enc^T, ctx = (P enc) W_v^T + b_v; automatic from Kv >= 2048) is the
     same arithmetic re-associated: forced on at small and ragged Kv it must agree with the K/V-cache path and with
     the oracle to the usual bar, and the automatic switch must pick it for a long sequence."""
-    for (qf, cfg, w), kv, n, L in ((video, 257, 3, 9), (audio, 100, 2, 5), (video, 130, 2, 4), (video, 200, 7, 4)):   # 7 items: two item groups
+    for (qf, cfg, w), kv, n, L in ((video, 257, 3, 9), (audio, 100, 2, 5), (video, 130, 2, 4), (video, 200, 7, 4)):
         ocfg = oracle_cfg(cfg)
         ids, tmask, att, feats = make_inputs(ocfg, n, L, kv, 11, True)
         enc = qf.modality_ln(feats.to(dev))
@@ -355,23 +355,6 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
     qf.set_cross_mode("auto")
     assert torch.equal(auto, forced)
     assert (auto - ref).abs().max().item() < 5e-3
-
-
-def test_item_groups_give_identical_results(video, dev):
-    """Items never interact, so running contiguous item blocks as separate forwards of the same handle on the group
-    streams (``item_groups``) must reproduce the single-launch-sequence outputs bit for bit, in both cross modes."""
-    qf, cfg, w = video
-    ocfg = oracle_cfg(cfg)
-    ids, tmask, att, feats = make_inputs(ocfg, 7, 6, 150, 21, True)
-    enc = qf.modality_ln(feats.to(dev))
-    for mode in ("kv_cache", "fold"):
-        qf.set_cross_mode(mode)
-        one = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_full=True, want_cls=True)
-        for G in (2, 3, 7, 9):
-            many = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_full=True, want_cls=True, item_groups=G)
-            for k in ("query", "full", "cls"):
-                assert torch.equal(one[k], many[k]), (mode, G, k)
-    qf.set_cross_mode("auto")
 
 
 def test_modality_streams_are_joined_before_fusion(dev):

@@ -118,3 +118,53 @@ def test_eva_vit_g_geometry_cpu():
                                                         "blocks": [type("B", (), {"fc1": type("F", (), {"out_features": 6144})()})()] * 39})()) / 1e9 - 520.7) < 0.1
     import inspect
     assert list(inspect.signature(create_eva_vit_g).parameters) == ["img_size", "drop_path_rate", "use_checkpoint", "precision"]
+
+
+def test_text_output_windows_float_and_multi_window():
+    """the reference's preprocessing writes float windows (``save_float=True``) and QVHighlights rows
+    hold several windows; the training target is the union of all of them."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP as X
+
+    assert X.parse_windows("[[24.3, 30.4]]") == [[24.3, 30.4]]
+    assert X.parse_windows("[[0, 10], [20, 30]]") == [[0.0, 10.0], [20.0, 30.0]]
+    assert X.parse_windows("[[12, 5]]") == [[5.0, 12.0]]            # reversed bounds are swapped, as utils/utils.py does
+    assert X.parse_windows("[[-1, -1]]") == []                       # "no window"
+    with pytest.raises(ValueError):
+        X.parse_windows("no windows here")
+    stub = type("S", (), {"_device": torch.device("cpu"), "parse_windows": X.parse_windows})()
+    samples = {"timestamps": [[0, 5, 10, 15, 20, 25, 30]], "text_output": ["[[4.5, 10.2], [24.9, 30]]"]}
+    tgt = X._targets(stub, samples, 1, 7)
+    assert tgt.tolist() == [[0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0]]
+
+
+def test_batched_encode_is_sample_major_and_sharded():
+    """Row A1: the reference's T sequential encoder calls at batch B (models/xinstructblip.py:262-275) followed by
+    ``cat(embeds)[indices]`` (:281-285) equal ONE sample-major [B*T] batch; a rank's [lo, hi) block touches only
+    its own frames."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP as X
+
+    calls = []
+
+    def enc(x):                       # stand-in encoder: per-frame mean -> [n, 2, 3]
+        calls.append(int(x.shape[0]))
+        return x.flatten(1).mean(1)[:, None, None].expand(-1, 2, 3).clone()
+
+    B, T = 2, 5
+    video = torch.arange(B * 3 * T * 4 * 4, dtype=torch.float32).view(B, 3, T, 4, 4)
+    stub = type("S", (), {"_device": torch.device("cpu"), "encode_chunk": 4, "video_encoder": staticmethod(enc), "audio_encoder": staticmethod(enc)})()
+    raw, idx, bs, num = X._encode(stub, {"video": video}, "video")
+    assert idx is None and (bs, num) == (B, T) and raw.shape == (B * T, 2, 3) and calls == [4, 4, 2]
+    # the reference's order: per-position loop, cat, then the sample-major gather
+    frames = torch.cat([enc(video[:, :, j]) for j in range(T)])
+    ref = frames[torch.tensor(O.reorder_indices(B, T))]
+    assert torch.equal(raw, ref)
+    calls.clear()
+    part, _, _, _ = X._encode(stub, {"video": video}, "video", 3, 8)
+    assert torch.equal(part, ref[3:8]) and sum(calls) == 5          # only this rank's five frames were encoded
+    audio = torch.randn(B, T, 6, 128)
+    ra, _, bs, num = X._encode(stub, {"audio": audio}, "audio")
+    fa = torch.cat([enc(audio[:, j]) for j in range(T)])[torch.tensor(O.reorder_indices(B, T))]
+    assert torch.equal(ra, fa) and (bs, num) == (B, T)
+    pre = torch.randn(B, T, 7, 16)
+    rp, _, _, _ = X._encode(stub, {"video_embeds": pre}, "video", 2, 9)
+    assert torch.equal(rp, pre.reshape(B * T, 7, 16)[2:9])
