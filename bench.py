@@ -13,8 +13,11 @@ or cached between steps.  The ViT-g / BEATs encoders (stock PyTorch, not part of
 kernels) are NOT in the timed region: the features are the synthetic input (BASELINE configs 1-4).
 Weak scaling: every GPU holds its own 32 clips of a 32*N-clip video; value = all clips / time.
 
-Also on the JSON line: `roofline` of the dominant kernel (the K/V projection GEMM, timed alone with
-events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
+Also on the JSON line: `roofline` of the dominant kernels -- with the folded cross-attention (Kv >= 2048, the
+headline shape) the block of one cross layer (per-head Q' GEMM, scores + split-softmax statistics, P.enc, per-head
+context GEMM), timed inside the steps by an event pair the library records on the launch stream; `frac` is EXECUTED
+flops / dense f16 MFMA peak, the reference formulation's algorithmic flops are reported beside it -- and
+`cpu_baseline` (the CPU oracle on a bounded sample, median of three passes, rank 0, N = 1).
 """
 from __future__ import annotations
 
@@ -61,9 +64,8 @@ def parse():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold384"],
-                    help="cross-attention formulation (auto = folded from Kv >= 2048)")
-    ap.add_argument("--item-groups", type=int, default=1, help="item groups of a long-sequence Q-Former on separate streams (1 = off)")
+    ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold_stream", "fold384"],
+                    help="cross-attention formulation (auto = folded from Kv >= 2048; fold_stream / fold384: A/B variants)")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
@@ -104,7 +106,6 @@ def main():
     # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
     model.kv_first = not args.no_kv_first
-    model.item_groups = args.item_groups
     model.prioritize_heavy = not args.no_priority
     for m in ("video", "audio"):
         getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
@@ -136,13 +137,9 @@ def main():
     # the library on the launch stream (= torch's current stream)
     lib = _lib.lib()
     qf = model.video_Qformer
-    # one (start, stop) pair per item group and step; with G groups the G blocks of cross layer 0 run concurrently on G
-    # streams, so the measured duration is the span from the first group's start to the last group's stop
-    G = max(1, args.item_groups)
-    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(G)] for _ in range(args.steps)]
-    for pairs in evs:   # create the underlying hipEvents (torch creates them lazily on first record)
-        for a, b in pairs:
-            a.record(); b.record()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:   # create the underlying hipEvents (torch creates them lazily on first record)
+        a.record(); b.record()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -152,9 +149,7 @@ def main():
     dt = time.perf_counter() - t0
     model.roofline_events = None
 
-    def span(pairs):   # pairs a step did not use keep their creation-time record: negative, never the maximum
-        return max(pairs[0][0].elapsed_time(b) for _, b in pairs)
-    kv_step_ms = sum(span(p) for p in evs) / len(evs)
+    kv_step_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -180,15 +175,16 @@ def main():
     ncross, H, E = 6, 768, ENC_WIDTH["video"]
     kv_flops = 2.0 * n_local * kv["video"] * E * (ncross * 2 * H)
     Q, R = 32, 12 * 32
-    folded = args.cross_mode in ("fold", "fold384") or (args.cross_mode == "auto" and kv["video"] >= 2048)
+    folded = args.cross_mode in ("fold", "fold_stream", "fold384") or (args.cross_mode == "auto" and kv["video"] >= 2048)
     if folded:
-        # folded cross-attention: the library's event pair brackets the five launches of cross layer 0.  Algorithmic
-        # work = what the reference formulation does for one layer (K and V projection of every token + the
-        # attention core); executed work = the re-associated products actually run.
+        # folded cross-attention: the library's event pair brackets the launches of cross layer 0.  Executed work = the
+        # re-associated products actually run (that is what `frac` prices); algorithmic work = what the reference
+        # formulation does for one layer (K and V projection of every token + the attention core).
         block_alg = 4.0 * n_local * kv["video"] * E * H + 4.0 * n_local * Q * kv["video"] * H
         block_exec = 4.0 * n_local * R * kv["video"] * E + 4.0 * n_local * Q * H * E
-        achieved = block_alg / (kv_step_ms * 1e-3) / 1e12
+        achieved = block_exec / (kv_step_ms * 1e-3) / 1e12
     else:
+        block_alg = block_exec = kv_flops
         achieved = kv_flops / (kv_step_ms * 1e-3) / 1e12  # priced on the in-step launches (timed region)
     del cache, enc
 
@@ -199,13 +195,16 @@ def main():
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
-    fold_pmc = os.path.join(ROOT, "profiles", "r01o_pmc_fold.json")
+    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
+    if not os.path.exists(fold_pmc):
+        fold_pmc = os.path.join(ROOT, "profiles", "r01o_pmc_fold.json")
     traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
     if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
-        traffic_src = "profiles/r01o_pmc_fold.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
+        traffic_src = f"profiles/{os.path.basename(fold_pmc)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
 
-    flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))
+    flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))   # reference formulation
+    flops_exec = flops_step - (ncross * (block_alg - block_exec) if folded else 0.0)
 
     # ---- the encode stage (row A1), timed SEPARATELY: stock PyTorch EVA ViT-g over every frame of the step ----
     encode = None
@@ -234,16 +233,23 @@ def main():
                 "weights": "synthetic BERT init, seed 0",
                 "cross_attention": "folded" if folded else "kv_cache",
             },
-            "tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
+            "executed_tflops_per_gpu": round(flops_exec * args.steps / dt / 1e12, 1),
+            "algorithmic_tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
             "roofline": ({"bound": "mfma",
-                          "kernel": "folded cross-attention of one layer, video: per-head Q' GEMM + batched scores GEMM (gemm_ws_kernel<176x384>, fp32 rows) + "
-                                    "softmax rows + batched P.enc GEMM (gemm_ws_kernel<176x384>) + per-head context GEMM (5 launches, cross layer 0 of 6)",
+                          "kernel": ("folded cross-attention of one layer, video, the launches between the library's event pair (cross layer 0 of 6): "
+                                     + ("per-head Q' GEMM (gemm_kernel<64,64>) + Q' re-pack + fold_stream_kernel<scores> + row statistics + fold_stream_kernel<pv> "
+                                        "+ per-head context GEMM" if args.cross_mode == "fold_stream" else
+                                        "per-head Q' GEMM (gemm_kernel<64,64>) + batched scores GEMM (gemm_ws_kernel<176x384, EPI_SOFTPART>: exp2(s - tile max) in f16 "
+                                        "+ tile statistics) + softmax_rescale_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384>, encoder tokens as the K-major "
+                                        "operand) + per-head context GEMM")),
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                          "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_alg,
-                          "note": "achieved = algorithmic flops of the layer in the reference formulation (K/V projection of every token + attention "
-                                  "core) / measured duration of the block; executed_tflops counts the re-associated products actually run",
-                          "executed_flops_per_launch": block_exec, "executed_tflops": round(block_exec / (kv_step_ms * 1e-3) / 1e12, 1),
+                          "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_exec,
+                          "note": "achieved / frac = EXECUTED flops of the block (the re-associated products) / its duration measured inside the timed steps; "
+                                  "algorithmic_tflops = what the reference formulation (K/V projection of every token + attention core) would need for the same layer",
+                          "algorithmic_flops_per_launch": block_alg, "algorithmic_tflops": round(block_alg / (kv_step_ms * 1e-3) / 1e12, 1),
+                          "hbm": None if not traffic else {"achieved": round(traffic / (kv_step_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                          "frac": round(traffic / (kv_step_ms * 1e-3) / 1e9 / 8000.0, 4)},
                           "kv_cache_mode_gemm": {"kernel": "gemm_ws_kernel<256x256x64, EPI_KV> (what --cross-mode kv_cache runs instead)",
                                                  "standalone_launch_ms": round(kv_ms, 4),
                                                  "standalone_tflops": round(kv_flops / (kv_ms * 1e-3) / 1e12, 1)}}
@@ -299,29 +305,43 @@ def vit_gf(total_flops, nframes):
 
 
 def cpu_baseline(args, kv, L):
-    """The oracle (kind "port": a CPU restatement in torch fp32, all host threads) on the same
-    workload, bounded to a few clips so the default run stays within minutes."""
+    """The oracle (kind "port": a CPU restatement in torch fp32, all host threads) on the same workload, bounded to a few
+    clips so the default run stays within minutes.  Protocol (SURVEY 8d / BASELINE.md): one warm-up pass, then the MEDIAN
+    of three timed passes over the sample; the reference item shape (Kv 257 / 256) is timed the same way beside it."""
     from mraudio_amd.models.xinstructblip import ENC_WIDTH
     from oracle import qformer_ref as O
 
     threads = host_threads()
     torch.set_num_threads(threads)
     log(f"cpu baseline: {threads} threads")
-    # bounded sample: ~0.47 s per 32-frame clip on 16 threads -> 24 clips = ~11 s of CPU work (reference item shape: 0.05 s per item)
-    n = args.cpu_clips if args.cpu_clips > 0 else (24 if args.workload == "clip32x32" else 256)
     cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
     ws = {"video": O.init_weights(cfgs["video"], seed=0), "audio": O.init_weights(cfgs["audio"], seed=1)}
-    g = torch.Generator().manual_seed(1234)
-    feats = {m: torch.randn(n, kv[m], ENC_WIDTH[m], generator=g) for m in ("audio", "video")}
-    ids = torch.randint(1000, 30000, (n, L), generator=g)
-    tm = torch.ones(n, L, dtype=torch.long)
-    with torch.no_grad():
-        O.encode_fuse_score(ws, cfgs, {m: feats[m][:1] for m in feats}, ids[:1], tm[:1], 1, 1)  # warm-up
-        t0 = time.perf_counter()
-        O.encode_fuse_score(ws, cfgs, feats, ids, tm, 1, n)
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{n} clips of the same workload, one pass after a 1-clip warm-up, torch fp32 oracle, {dt:.1f} s"}
+
+    def timed(n, kvs, passes=3):
+        g = torch.Generator().manual_seed(1234)
+        feats = {m: torch.randn(n, kvs[m], ENC_WIDTH[m], generator=g) for m in ("audio", "video")}
+        ids = torch.randint(1000, 30000, (n, L), generator=g)
+        tm = torch.ones(n, L, dtype=torch.long)
+        ts = []
+        with torch.no_grad():
+            O.encode_fuse_score(ws, cfgs, {m: feats[m][:2] for m in feats}, ids[:2], tm[:2], 1, 2)  # warm-up
+            for _ in range(passes):
+                t0 = time.perf_counter()
+                O.encode_fuse_score(ws, cfgs, feats, ids, tm, 1, n)
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], ts
+
+    # bounded samples: ~0.47 s per 32-frame clip on 16 threads -> 16 clips x 3 passes = ~23 s; reference items: 0.05 s each
+    n = args.cpu_clips if args.cpu_clips > 0 else (16 if args.workload == "clip32x32" else 128)
+    med, ts = timed(n, kv)
+    out = {"value": round(n / med, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+           "sample": f"{n} clips of the same workload, torch fp32 oracle: 1 warm-up + 3 timed passes, median {med:.1f} s (passes {[round(t, 1) for t in ts]})"}
+    if args.workload == "clip32x32":
+        n_ref = 96
+        med_r, ts_r = timed(n_ref, {"video": 257, "audio": 256})
+        out["reference_item_shape"] = {"value": round(n_ref / med_r, 2), "unit": "items/s",
+                                       "sample": f"{n_ref} items at the reference's own item shape (Kv 257 video + 256 audio), same protocol, median {med_r:.1f} s"}
+    return out
 
 
 if __name__ == "__main__":

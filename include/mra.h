@@ -133,19 +133,20 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
 /* How the six cross-attention layers are computed (HF modeling_instructblip.py:464-515 arithmetic either way):
  *   1  K/V cache: K and V of every cross layer projected up front by one GEMM, then a flash-style core per layer;
  *   2  folded:    per layer S = (Q W_k) enc^T, P = softmax(S / 8), context = (P enc) W_v^T + b_v -- half the flops
- *                 at any Kv (the 32 queries are fewer than the 64 head dimensions), five launches per layer,
- *                 scores kept in fp32;
- *   0  automatic (default): folded from Kv >= 2048.
- *   3  as 2 with the 128 x 384 loader-wave tile instead of the 128 x 128 tiles (A/B runs: no faster).
- * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache.
- * A/B switches of the folded path, read from the environment at mra_qformer_create / first launch (defaults in brackets):
- *   MRA_SC_TILE [5] / MRA_PV_TILE [5]   2 = plain 128 x 128 tiles for the scores / P.enc GEMM instead of the 176 x 384 tile
- *   MRA_SPLIT_SOFTMAX [1]               0 = fp32 score rows + softmax_rows kernel instead of the split softmax
- *   MRA_FOLD_NT [1]                     0 = default cache policy for the once-read operand slab */
+ *                 at any Kv (the 32 queries are fewer than the 64 head dimensions).  With 12 heads and enc_width % 176 == 0
+ *                 the two big products run on the 176 x 384 loader-wave GEMM tile with the softmax split over the
+ *                 176-column tiles (tile statistics in the scores epilogue, one rescale pass over P); otherwise on
+ *                 128 x 128 tiles with fp32 score rows;
+ *   0  automatic (default): folded from Kv >= 2048;
+ *   3  as 2 on the 128 x 384 loader-wave tile (A/B runs: no faster);
+ *   4  as 2 on the streaming kernels of fold_stream.hip (f16 only: row operands straight to registers two K steps
+ *      ahead, slab ring of four LDS slots, power-of-two tile factors applied in registers, no rescale pass).  Measured
+ *      13 % SLOWER than mode 2 -- both forms sit on the per-CU load path, DESIGN.md section 8 -- kept, tested, opt-in.
+ * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
  * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one
- * handle concurrently on different streams (item groups, mraudio_amd/qformer.py) calls it once before forking. */
+ * handle concurrently on different streams calls it once before forking. */
 int mra_qformer_prepare(mra_qformer* h, void* stream);
 
 /* Scheduling hook: when `ev` (hipEvent_t as void*) is non-NULL every following mra_qformer_forward records it

@@ -649,17 +649,11 @@ int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (wei
     if (epi != EPI_OP) return -2;
     return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true>, a, 768, lds, stream);
   }
-  static const bool nt = getenv("MRA_FOLD_NT") ? atoi(getenv("MRA_FOLD_NT")) != 0 : true;   // A/B switch
-  if (nt) {
-    if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
-    if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8, true>, a, 768, lds, stream);
-    if (epi == EPI_OP) return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true>, a, 768, lds, stream);
-    return -2;
-  }
-  if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8>, a, 768, lds, stream);
-  if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8>, a, 768, lds, stream);
-  if (epi != EPI_OP) return -2;
-  return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8>, a, 768, lds, stream);
+  // the slab (weight-side rows) is read by this workgroup only: non-temporal loads (7.40 -> 7.17 ms / step)
+  if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
+  if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8, true>, a, 768, lds, stream);
+  if (epi == EPI_OP) return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true>, a, 768, lds, stream);
+  return -2;
 }
 
 template <typename T, int TN, int TM, int WGN, int WGM>

@@ -153,6 +153,28 @@ int launch_softmax_rescale(void* P, long long ld_p, const float* stat_m, const f
 int launch_transpose_pad(const void* src, void* dst, int R, int C, int ld_d, long long src_bs, long long dst_bs, int batch, int op_dtype,
                          hipStream_t stream);
 
+// ---- folded cross-attention, streaming form (fold_stream.hip) ---------------------------------------
+// scores + split-softmax statistics + P . enc of one cross layer for `items` items of 384 (head, query) rows:
+//   phase bit 0: P~ = exp2(alpha * Q' enc^T - ceil(tile max)) in f16 + per-(row, 176-column tile) statistics, then the row
+//                statistics (tile factors 2^(m_tile - m_row) as f16, 1 / L);   phase bit 1: U = (1 / L) sum g P~ enc.
+struct FoldStreamArgs {
+  const void* qp;    // Q' [items][384][E] f16, row-major (the per-head Q' GEMM's output)
+  void* qpb;         // workspace of the same size: Q' re-packed into the row operand's blocked layout
+  const void* enc;   // encoder tokens [items][kv][E] f16
+  void* p;           // P~ [items][384 x kvp] f16 (workspace; blocked layout [row / 16][k / 8][16][8])
+  void* u;           // U  [items][384][E] f16
+  float* stat_m;     // [items * 384][fold_stream_stat_ld(kvp)]
+  float* stat_l;
+  void* gexp;        // f16 [items * 384][stat_ld]
+  float* ginv;       // [items * 384]
+  int items, kv, kvp, E;
+  float alpha;
+  int phase;         // 3 = both
+};
+bool fold_stream_supported(int rows, int E, int kv, int kvp, int op_dtype);
+int fold_stream_stat_ld(int kvp);
+int launch_fold_stream(const FoldStreamArgs& a, hipStream_t stream);
+
 // ---- attention ------------------------------------------------------------------------------
 struct AttnArgs {
   const void* Q;  // [item][q row][head*64 + d], op dtype

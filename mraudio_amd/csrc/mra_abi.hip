@@ -146,6 +146,8 @@ struct Work {
   char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
   float* s32;                      // scores [N][R][kvp]
   float* stat;                     // split softmax: tile maxima [N][R][ntiles], then tile sums
+  float *st_m, *st_l, *ginv;       // streaming kernels: statistics [N * R][stat_ld], 1 / L [N * R]
+  char* gexp;                      // tile factors f16 [N * R][stat_ld]
   int nsplit;
   size_t bytes;
 };
@@ -167,8 +169,19 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
   w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = nullptr;
-  w.s32 = w.stat = nullptr;
-  if (h->ncross > 0 && use_fold(h, Kv)) {
+  w.s32 = w.stat = w.st_m = w.st_l = w.ginv = nullptr;
+  w.gexp = nullptr;
+  if (h->ncross > 0 && use_fold(h, Kv) && fold_streams(h, Kv)) {
+    const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv), sld = fold_stream_stat_ld((int)kvp);
+    w.qp16 = cv.take<char>((size_t)N * R * E, 2);
+    w.encT = cv.take<char>((size_t)N * R * E, 2);     // here: Q' in the streaming kernels' blocked layout
+    w.st_m = cv.take<float>((size_t)N * R * sld);
+    w.st_l = cv.take<float>((size_t)N * R * sld);
+    w.gexp = cv.take<char>((size_t)N * R * sld, 2);
+    w.ginv = cv.take<float>((size_t)N * R);
+    w.p16 = cv.take<char>((size_t)N * R * kvp, 2);
+    w.u16 = cv.take<char>((size_t)N * R * E, 2);
+  } else if (h->ncross > 0 && use_fold(h, Kv)) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
     if (!fold_kmajor(h)) w.encT = cv.take<char>((size_t)N * E * kvp, 2);
     w.qp16 = cv.take<char>((size_t)N * R * E, 2);
@@ -259,10 +272,6 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
       return fail(MRA_ENOMEM, std::string("fold weight arena: ") + hipGetErrorString(e));
     }
   }
-  if (const char* env = getenv("MRA_PV_TILE")) h->pv_tile = atoi(env);
-  if (const char* env = getenv("MRA_SC_TILE")) h->sc_tile = atoi(env);
-  if (const char* env = getenv("MRA_PV_KMAJOR")) h->pv_kmajor = atoi(env) != 0;
-  if (const char* env = getenv("MRA_SPLIT_SOFTMAX")) h->split_softmax = atoi(env) != 0;   // A/B runs: 2 = 128 x 128 tiles for P . enc
   // segment table of mra_qformer_load_flat: every bert.* parameter in chunks of FLAT_SEG elements
   std::vector<FlatSeg> segs;
   for (auto& kv : h->params) {
@@ -425,10 +434,11 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
   if (rc) return chk(rc, "embed_ln");
 
   const bool fold = h->ncross > 0 && use_fold(h, kv);
+  const bool stream_fold = fold && fold_streams(h, kv);
   const int R = c.heads * Q, kvp = fold_kvp(kv);
   if (fold) {
     // folded cross-attention: enc^T per item (the K-contiguous operand of P . enc), key weights regrouped per head
-    if (!fold_kmajor(h)) {
+    if (!stream_fold && !fold_kmajor(h)) {
       rc = launch_transpose_pad(enc, w.encT, kv, E, kvp, (long long)kv * E, (long long)E * kvp, N, op, stream);
       if (rc) return chk(rc, "enc transpose");
     }
@@ -514,6 +524,17 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = 1;
         rc = launch_gemm(&d, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold q' gemm");
+        if (stream_fold) {
+          // 6b-6d on the streaming kernels (fold_stream.hip): P~ = exp2(s - ceil(tile max)) + tile statistics, row statistics,
+          // U = (1 / L) sum g P~ enc with the power-of-two tile factors applied in registers.  P~ is written once, read once.
+          FoldStreamArgs fs{};
+          fs.qp = w.qp16; fs.qpb = w.encT; fs.enc = enc; fs.p = w.p16; fs.u = w.u16;
+          fs.stat_m = w.st_m; fs.stat_l = w.st_l; fs.gexp = w.gexp; fs.ginv = w.ginv;
+          fs.items = N; fs.kv = kv; fs.kvp = kvp; fs.E = E;
+          fs.alpha = 0.125f * 1.4426950408889634f; fs.phase = 3;
+          rc = launch_fold_stream(fs, stream);
+          if (rc) return chk(rc, "fold scores / P.enc (streaming kernels)");
+        } else {
         // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, rows padded to kvp columns
         GemmProb sc{};
         sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
@@ -552,6 +573,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
         rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold p.enc gemm");
+        }
         // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]
         GemmProb cx{};
         cx.A = w.u16; cx.a = items_view((long long)R * E, Q, E); cx.a_bs = (long long)Q * E;
@@ -705,9 +727,11 @@ int mra_qformer_prepare(mra_qformer* h, void* stream) {
 
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode) {
   if (!h) return fail(MRA_EINVAL, "null handle");
-  if (mode < 0 || mode > 3) return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache), 2 (folded) or 3 (folded, 128x384 tiles)");
-  h->cross_mode = mode == 3 ? 2 : mode;
+  if (mode < 0 || mode > 4)
+    return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache), 2 (folded), 3 (folded, 128x384 loader-wave tiles) or 4 (folded, streaming kernels)");
+  h->cross_mode = mode >= 3 ? 2 : mode;
   h->fold_tile = mode == 3 ? 4 : 2;
+  h->fold_stream = mode == 4;     // measured 13 % slower than the loader-wave GEMMs + rescale pass: opt-in
   return MRA_OK;
 }
 

@@ -94,6 +94,7 @@ struct mra_qformer {
   bool pv_kmajor = true;                          // P . enc reads the encoder tokens themselves (K-major weights, no enc^T copy); MRA_PV_KMAJOR=0
   int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
+  bool fold_stream = false;                       // folded path on the streaming kernels of fold_stream.hip (mra_qformer_set_cross_mode 4)
   int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
   hipEvent_t kv_done = nullptr;                   // optional scheduling hook (mra_qformer_set_kv_done_event)
   hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
@@ -111,12 +112,16 @@ struct mra_qformer {
 namespace mra_host {
 // folded cross-attention pays once the encoder sequence is long (fewer flops at any Kv, but five launches per layer)
 inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
-// padded score-row length: whole 128- and 176-row tiles of the scores GEMM, and a multiple of 64 (K of P . enc)
+// padded score-row length: whole 128- and 176-row tiles of the scores GEMM, and a multiple of 128 (K of P . enc)
 // P . enc on the 176 x 384 tile with K-major weights: no transposed copy of the encoder tokens is needed
 inline bool fold_kmajor(const mra_qformer* h) {
   return h->pv_kmajor && h->pv_tile == 5 && h->cfg.heads * h->cfg.n_query == 384 && h->cfg.enc_width % 176 == 0;
 }
-inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 63) / 64 * 64; }
+inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 127) / 128 * 128; }
+// the streaming kernels (fold_stream.hip): f16 operands, 384 (head, query) rows, E a multiple of 176
+inline bool fold_streams(const mra_qformer* h, int kv) {
+  return h->fold_stream && mra::fold_stream_supported(h->cfg.heads * h->cfg.n_query, h->cfg.enc_width, kv, fold_kvp(kv), h->op());
+}
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);
 }  // namespace mra_host

@@ -27,8 +27,72 @@ struct Shape {
   int M, N, K, epi, cfg;
 };
 
+#include <cstring>
+
+// A/B of the folded cross-attention's two big products at the headline shape (32 items x Kv 8224 x E 1408, 384 rows):
+// streaming kernels (fold_stream.hip) against the loader-wave GEMMs + rescale pass they replaced.  Random data.
+static void fold_ab(int rounds) {
+  const int items = 32, kv = 8224, E = 1408, R = 384;
+  const int kvp = (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 127) / 128 * 128, sld = fold_stream_stat_ld(kvp), nt = (kv + 175) / 176;
+  std::mt19937 rng(3);
+  std::normal_distribution<float> d(0.f, 1.f);
+  std::vector<_Float16> hq((size_t)items * R * E), hx((size_t)1 << 24);
+  for (auto& v : hq) v = (_Float16)(d(rng) * 0.5f);
+  for (auto& v : hx) v = (_Float16)d(rng);
+  _Float16 *Q, *Qb, *X, *P, *U, *G;
+  float *M, *L, *I;
+  CK(hipMalloc((void**)&Qb, hq.size() * 2));
+  CK(hipMalloc((void**)&Q, hq.size() * 2)); CK(hipMemcpy(Q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+  const size_t nx = (size_t)items * kv * E;
+  CK(hipMalloc((void**)&X, nx * 2));
+  for (size_t off = 0; off < nx; off += hx.size()) CK(hipMemcpy(X + off, hx.data(), std::min(hx.size(), nx - off) * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&P, (size_t)items * R * kvp * 2)); CK(hipMalloc((void**)&U, (size_t)items * R * E * 2));
+  CK(hipMalloc((void**)&G, (size_t)items * R * sld * 2)); CK(hipMalloc((void**)&M, (size_t)items * R * sld * 4));
+  CK(hipMalloc((void**)&L, (size_t)items * R * sld * 4)); CK(hipMalloc((void**)&I, (size_t)items * R * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timed = [&](auto&& fn) {
+    double best = 1e30;
+    for (int r = 0; r < rounds; ++r) {
+      fn();
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) fn();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, (double)ms / 5);
+    }
+    return best;
+  };
+  FoldStreamArgs a{};
+  a.qp = Q; a.qpb = Qb; a.enc = X; a.p = P; a.u = U; a.stat_m = M; a.stat_l = L; a.gexp = G; a.ginv = I;
+  a.items = items; a.kv = kv; a.kvp = kvp; a.E = E; a.alpha = 0.125f * 1.4426950408889634f;
+  a.phase = 3; if (launch_fold_stream(a, 0)) { printf("fold stream launch failed\n"); return; }
+  CK(hipDeviceSynchronize());
+  a.phase = 1; const double t_s = timed([&] { launch_fold_stream(a, 0); });
+  a.phase = 2; const double t_p = timed([&] { launch_fold_stream(a, 0); });
+  a.phase = 3; const double t_b = timed([&] { launch_fold_stream(a, 0); });
+  // the loader-wave formulation
+  GemmProb sc{};
+  sc.A = Q; sc.a = RowView{0, R, E}; sc.a_bs = (long long)R * E; sc.W = X; sc.w_bs = (long long)kv * E;
+  sc.M = R; sc.N = kv; sc.K = E; sc.batch = items; sc.n_ragged = 1; sc.tile_cfg = 5;
+  sc.C = P; sc.c = RowView{0, R, kvp}; sc.c_bs_bytes = (long long)R * kvp * 2; sc.alpha = a.alpha; sc.stat_m = M; sc.stat_l = L;
+  GemmProb pv{};
+  pv.A = P; pv.a = RowView{0, R, kvp}; pv.a_bs = (long long)R * kvp; pv.W = X; pv.w_bs = (long long)kv * E; pv.w_ld = E; pv.k_rows = kv;
+  pv.C = U; pv.c = RowView{0, R, E}; pv.c_bs_bytes = (long long)R * E * 2; pv.M = R; pv.N = E; pv.K = kvp; pv.batch = items; pv.tile_cfg = 5;
+  gemm_force_config(-1); gemm_force_variant(5);
+  const double o_s = timed([&] { launch_gemm(&sc, 1, EPI_SOFTPART, OP_F16, 0); });
+  const double o_r = timed([&] { launch_softmax_rescale(P, kvp, M, L, items * R, nt, 176, kvp, OP_F16, 0); });
+  const double o_p = timed([&] { launch_gemm(&pv, 1, EPI_OP, OP_F16, 0); });
+  const double fl = 2.0 * items * R * (double)kv * E;
+  printf("fold A/B (ms, executed TF/s): streaming scores+stats %.3f (%.0f)  pv %.3f (%.0f)  both %.3f | loader-wave scores %.3f (%.0f)  rescale %.3f  pv %.3f (%.0f)  sum %.3f\n",
+         t_s, fl / t_s / 1e9, t_p, fl / t_p / 1e9, t_b, o_s, fl / o_s / 1e9, o_r, o_p, fl / o_p / 1e9, o_s + o_r + o_p);
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
   const int only = argc > 2 ? atoi(argv[2]) : -1;      // run a single shape (profiling)
   const int only_variant = argc > 3 ? atoi(argv[3]) : -1;
   const Shape shapes[] = {

@@ -378,6 +378,58 @@ static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int
   report(name, worst, f32 ? 2e-4 : 3e-3);
 }
 
+// Folded cross-attention on the streaming kernels (fold_stream.hip): scores with split-softmax statistics, row statistics,
+// P . enc with the tile factors applied in registers -- against softmax(alpha' Q' enc^T) enc in double on the same f16 inputs.
+// `gain` scales Q' so that rows are flat (1) or peaked (tile maxima far apart: factors down to 2^-24 and exact zeros).
+static void test_fold_stream(int items, int kv, int E, float gain) {
+  const int R = 384, op = OP_F16;
+  const int kvp = (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 127) / 128 * 128;
+  if (!fold_stream_supported(R, E, kv, kvp, op)) { report("fold stream: shape not supported", 1e30, 0); return; }
+  const int sld = fold_stream_stat_ld(kvp);
+  std::vector<uint16_t> Q((size_t)items * R * E), X((size_t)items * kv * E);
+  for (auto& v : Q) v = to_op(frand(0.3f) * gain, op);
+  for (auto& v : X) v = to_op(frand(), op);
+  Dev<uint16_t> dQ(Q), dQb((size_t)items * R * E), dX(X), dP((size_t)items * R * kvp), dU((size_t)items * R * E), dG((size_t)items * R * sld);
+  Dev<float> dM((size_t)items * R * sld), dL((size_t)items * R * sld), dI((size_t)items * R);
+  CK(hipMemset(dP.p, 0xff, (size_t)items * R * kvp * 2));     // NaN patterns: every P~ column the pv product reads must have been written
+  FoldStreamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.qp = dQ.p; a.qpb = dQb.p; a.enc = dX.p; a.p = dP.p; a.u = dU.p; a.stat_m = dM.p; a.stat_l = dL.p; a.gexp = dG.p; a.ginv = dI.p;
+  a.items = items; a.kv = kv; a.kvp = kvp; a.E = E; a.alpha = 0.125f * 1.4426950408889634f; a.phase = 3;
+  const int rc = launch_fold_stream(a, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> u = dU.get();
+  double worst = rc ? 1e30 : 0, peak = 0;
+  std::vector<double> s(kv), ref(E);
+  for (int it = 0; it < items && !rc; ++it)
+    for (int r = 0; r < R; r += (items * R > 800 ? 7 : 1)) {     // every 7th row on the larger cases
+      double mx = -1e300;
+      for (int k = 0; k < kv; ++k) {
+        double acc = 0;
+        for (int e = 0; e < E; ++e) acc += (double)from_op(Q[((size_t)it * R + r) * E + e], op) * from_op(X[((size_t)it * kv + k) * E + e], op);
+        s[k] = acc * 0.125;
+        mx = std::max(mx, s[k]);
+      }
+      double L = 0, pm = 0;
+      for (int k = 0; k < kv; ++k) { s[k] = exp(s[k] - mx); L += s[k]; }
+      std::fill(ref.begin(), ref.end(), 0.0);
+      for (int k = 0; k < kv; ++k) {
+        const double p = s[k] / L;
+        pm = std::max(pm, p);
+        for (int e = 0; e < E; ++e) ref[e] += p * from_op(X[((size_t)it * kv + k) * E + e], op);
+      }
+      peak = std::max(peak, pm);
+      for (int e = 0; e < E; ++e) {
+        const double got = from_op(u[((size_t)it * R + r) * E + e], op);
+        const double err = fabs(got - ref[e]) / (0.05 + fabs(ref[e]));
+        worst = std::isfinite(got) ? std::max(worst, err) : 1e30;
+      }
+    }
+  char name[160];
+  snprintf(name, sizeof(name), "fold stream items%d kv%d E%d gain%.0f (max row probability %.3f)", items, kv, E, gain, peak);
+  report(name, worst, 6e-3);     // f16 P~ (11 bits) and f16 output against |U| ~ 0.05 .. 1
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-gradient GEMM dW = dY^T X (+ bias gradient), row-major and head-major dY, ragged M, accumulate
 static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accumulate) {
@@ -868,6 +920,11 @@ int main(int argc, char** argv) {
   test_gemm_kmajor(OP_F16, 200, 176, 64, 64, 3);
   test_gemm_kmajor(OP_BF16, 384, 528, 192, 150, 1);
   test_gemm_batched(4, EPI_F32, OP_F16, 100, 177, 64, 2, true);
+  test_fold_stream(2, 300, 704, 1.f);       // two score tiles, ragged kv, two E slabs
+  test_fold_stream(1, 2100, 704, 1.f);      // 12 score tiles, K loop of 34 steps (not a multiple of the set rotation)
+  test_fold_stream(2, 700, 704, 12.f);      // peaked rows: tile factors spread over many powers of two
+  test_fold_stream(1, 1000, 704, 60.f);     // near one-hot rows: most tile factors flush to zero
+  test_fold_stream(3, 176, 1408, 2.f);      // exactly one tile, the video width
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);

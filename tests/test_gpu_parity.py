@@ -332,7 +332,10 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
         ref = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
         qf.set_cross_mode("fold")
         got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
+        qf.set_cross_mode("fold_stream")    # video geometry: the streaming kernels; audio (E = 768): falls back to "fold"
+        strm = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
         qf.set_cross_mode("auto")
+        assert (strm["query"] - ref["query"]).abs().max().item() < 5e-3 and (strm["cls"] - ref["cls"]).abs().max().item() < 5e-3
         assert (got["query"] - ref["query"]).abs().max().item() < 5e-3, (kv, (got["query"] - ref["query"]).abs().max().item())
         assert (got["cls"] - ref["cls"]).abs().max().item() < 5e-3
         enc_ref = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"])
