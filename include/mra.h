@@ -211,6 +211,38 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
  * Algorithmic flop count of one mra_qformer_forward (2 flops per MAC; formula in DESIGN.md). */
 double mra_qformer_flops(mra_qformer* h, int32_t items, int32_t L, int32_t kv, int32_t with_last_text);
 
+/* ---- EVA ViT-g/14 visual encoder (row A1 / N4) -----------------------------------------------------------
+ * replaces: self.video_encoder(frame) inside the per-position loop of XInstructBLIP.generate / forward
+ * (models/xinstructblip.py:262-266, :412-420), the module create_eva_vit_g(224, 0, False, "fp16") builds (:658-666).
+ * One call encodes ALL frames of a step (the reference's T sequential calls at batch B, collapsed).  Parameter names are
+ * the state_dict keys of mraudio_amd/models/eva_vit.py (cls_token, pos_embed, patch_embed.{weight,bias},
+ * blocks.{i}.{norm1,norm2}.{weight,bias}, blocks.{i}.attn.{qkv.weight,q_bias,v_bias,proj.weight,proj.bias},
+ * blocks.{i}.{fc1,fc2}.{weight,bias}); EvaViTg.hf_state_dict / load_hf_state_dict map them to the HF vision tower. */
+typedef struct mra_vit mra_vit;
+typedef struct mra_vit_cfg {
+  int32_t dim;       /* 1408; multiple of 176 and 64 */
+  int32_t heads;     /* 16; head dimension dim / heads = 88 (<= 96, multiple of 8) */
+  int32_t mlp;       /* 6144 */
+  int32_t depth;     /* 39 (LAVIS drops the 40th EVA block) */
+  int32_t patch;     /* 14 */
+  int32_t img;       /* 224 -> (224 / 14)^2 + 1 = 257 tokens */
+  float ln_eps;      /* 1e-6 */
+  int32_t op_dtype;  /* MRA_F16 (the reference's precision="fp16") or MRA_BF16: MFMA operand type; residual stream fp32 */
+} mra_vit_cfg;
+void mra_vit_cfg_default(mra_vit_cfg* cfg);
+int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out);
+void mra_vit_destroy(mra_vit* h);
+int mra_vit_load(mra_vit* h, const char* name, const void* src, int32_t dtype, const int64_t* shape, int32_t ndim, void* stream);
+/* number of parameters not loaded yet (0 = ready) */
+int mra_vit_missing(mra_vit* h);
+size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames);
+/* frames [n, 3, img, img] (MRA_F32 or MRA_F16, normalised pixels) -> out [n, tokens, dim] fp32: the last block's output,
+ * no final norm (the reference's separate video_ln, mra_modality_ln, consumes it in place). */
+int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, float* out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* algorithmic flops of one forward over `frames` frames (2 per MAC) */
+double mra_vit_flops(mra_vit* h, int32_t frames);
+
 #ifdef __cplusplus
 }
 #endif

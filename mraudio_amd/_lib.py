@@ -28,6 +28,11 @@ class mra_cfg(C.Structure):
     ]
 
 
+class mra_vit_cfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32), ("depth", C.c_int32), ("patch", C.c_int32),
+                ("img", C.c_int32), ("ln_eps", C.c_float), ("op_dtype", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/mra.h declares (tests check this)
 PROTOTYPES = {
     "mra_cfg_default": (None, [C.POINTER(mra_cfg), C.c_int32]),
@@ -67,6 +72,14 @@ PROTOTYPES = {
     "mra_qformer_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mra_qformer_flops": (C.c_double, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mra_vit_cfg_default": (None, [C.POINTER(mra_vit_cfg)]),
+    "mra_vit_create": (C.c_int, [C.POINTER(mra_vit_cfg), C.POINTER(C.c_void_p)]),
+    "mra_vit_destroy": (None, [C.c_void_p]),
+    "mra_vit_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
+    "mra_vit_missing": (C.c_int, [C.c_void_p]),
+    "mra_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "mra_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mra_vit_flops": (C.c_double, [C.c_void_p, C.c_int32]),
 }
 
 _lib = None

@@ -653,6 +653,8 @@ int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (wei
   if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
   if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8, true>, a, 768, lds, stream);
   if (epi == EPI_OP) return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true>, a, 768, lds, stream);
+  // N = 1408 = 8 x 176 projections of the ViT blocks (vit.hip): the 176 weight rows are shared by every row tile -> default cache policy
+  if (epi == EPI_RES_F32) return launch_k(gemm_ws_kernel<T, EPI_RES_F32, false, 176, 384, 8, false>, a, 768, lds, stream);
   return -2;
 }
 

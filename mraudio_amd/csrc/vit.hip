@@ -1,0 +1,444 @@
+// EVA ViT-g/14 visual encoder (row A1 / N4): the callee of the reference's per-frame loop,
+// `ln(encoder(frame))` at models/xinstructblip.py:262-266, built by create_eva_vit_g(224, 0, False, "fp16") (:658-666).
+// LAVIS is absent offline; the arithmetic is the published EVA-CLIP-g geometry as LAVIS instantiates it (39 pre-LN blocks,
+// width 1408, 16 heads x 88, MLP 6144, 14 x 14 patches of a 224 x 224 frame -> 257 tokens, q / v bias without k bias, exact
+// GELU, LayerNorm eps 1e-6, no final norm) -- pinned to transformers' InstructBlipVisionModel (HF modeling_instructblip.py:
+// 101-440) by mraudio_amd/models/eva_vit.py and tests/golden/vit_g.npz.
+//
+// One batched forward over ALL frames of a step (the reference calls the encoder T times at batch B):
+//   im2col -> patch GEMM (+ bias + position embedding in the epilogue) -> [CLS] rows
+//   39 x { LN -> QKV GEMM -> attention core -> projection GEMM + residual -> LN -> fc1 GEMM + GELU -> fc2 GEMM + residual }
+// 97 % of the flops are the four GEMMs per block at M = frames x 257 rows: the loader-wave kernels of gemm.hip (256 x 256 for
+// N = 4608 / 6144, 176 x 384 for N = 1408 = 8 x 176) with bias / GELU / residual fused into their epilogues.  The fp32
+// residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
+// Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
+// per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
+// MFMA steps; the zero columns add nothing to any dot product.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mra_common.h"
+#include "mra_handle.h"
+
+using namespace mra;
+using namespace mra_host;
+
+namespace {
+
+constexpr int HD_PAD = 96;      // padded head dimension
+constexpr int KS_PAD = 288;     // keys padded to 9 MFMA K steps of 32 (257 valid)
+constexpr int KV_PITCH = 208;   // LDS row pitch of K / V tiles: 13 sixteen-byte slots -> conflict-free ds_read_b128 over 16 rows
+constexpr int P_PITCH = 592;    // LDS row pitch of a wave's P tile: 37 slots
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ---------------------------------------------------------------------------------------------------------
+// attention core: one workgroup per (frame, head), K and V of the head staged once in LDS, each wave takes 16-query
+// blocks: S^T = K Q^T (keys on the MFMA row index), softmax over the lane's key column group, P through a wave-private
+// LDS tile into the B operand of O^T = V^T P^T (V^T by transposed LDS reads).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) vit_attn_kernel(const T* qkv, T* ctx, int S, int heads, int hd, float sl2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + KS_PAD * KV_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* Pw = smem + 2 * KS_PAD * KV_PITCH + wave * 16 * P_PITCH;
+  const int frame = blockIdx.x / heads, head = blockIdx.x - frame * heads;
+  const int ld = 3 * heads * HD_PAD;
+  const T* base = qkv + (long long)frame * S * ld + head * HD_PAD;
+  using V8 = typename Vec8<T>::type;
+  // ---- K, V rows of this head -> LDS (rows past S zeroed) ----
+  for (int c = tid; c < KS_PAD * 12; c += 256) {
+    const int row = c / 12, ch = c - row * 12;
+    V8 k, v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { k[e] = from_f32<T>(0.f); v[e] = k[e]; }
+    if (row < S) {
+      const T* p = base + (long long)row * ld + ch * 8;
+      k = *reinterpret_cast<const V8*>(p + heads * HD_PAD);
+      v = *reinterpret_cast<const V8*>(p + 2 * heads * HD_PAD);
+    }
+    *reinterpret_cast<V8*>(Ks + row * KV_PITCH + ch * 16) = k;
+    *reinterpret_cast<V8*>(Vs + row * KV_PITCH + ch * 16) = v;
+  }
+  __syncthreads();
+  const int lm = lane & 15, lc = lane >> 4;
+  const int nblocks = (S + 15) >> 4;
+  for (int qb = wave; qb < nblocks; qb += 4) {
+    const int q0 = qb * 16;
+    // Q fragments (B operand): lane (query lm, chunk lc) holds Q[q0 + lm][32 ks + 8 lc .. + 7]
+    V8 qf[3];
+    {
+      const T* qp = base + (long long)min(q0 + lm, S - 1) * ld + 8 * lc;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 32 * ks);
+    }
+    f32x4 sc[KS_PAD / 16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < KS_PAD / 16; ++i) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(Ks + (16 * i + lm) * KV_PITCH + (4 * ks + lc) * 16);
+        a = mfma16<T>(kf, qf[ks], a);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = 16 * i + 4 * lc + e < S ? a[e] * sl2 : -3.0e38f;
+        mx = fmaxf(mx, a[e]);
+      }
+      sc[i] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < KS_PAD / 16; ++i) {
+      typename Vec4<T>::type o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = __builtin_amdgcn_exp2f(sc[i][e] - mx);   // masked keys: exp2(-huge) = 0
+        o[e] = from_f32<T>(p);
+        l += (float)o[e];
+      }
+      *reinterpret_cast<typename Vec4<T>::type*>(Pw + lm * P_PITCH + (16 * i + 4 * lc) * 2) = o;
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the P tile is read back by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]
+    f32x4 ot[HD_PAD / 16];
+#pragma unroll
+    for (int df = 0; df < HD_PAD / 16; ++df) ot[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS_PAD / 32; ++ks) {
+      const V8 pf = *reinterpret_cast<const V8*>(Pw + lm * P_PITCH + (32 * ks + 8 * lc) * 2);
+      // V^T fragment of d block df: two transposed 4 x 16 blocks (keys 32 ks + 8 lc + 0..3 and + 4..7)
+      const char* vb = Vs + (32 * ks + 8 * lc + (lm >> 2)) * KV_PITCH + (lane & 3) * 8;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df) {
+        const i16x4 c0 = lds_read_tr4(vb + df * 32), c1 = lds_read_tr4(vb + df * 32 + 4 * KV_PITCH);
+        i16x8 v;
+        v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+        ot[df] = mfma16<T>(__builtin_bit_cast(V8, v), pf, ot[df]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the next block's P writes must not overtake these reads
+    const float inv = 1.0f / l;
+    if (q0 + lm < S) {
+      T* crow = ctx + ((long long)frame * S + q0 + lm) * (heads * hd) + head * hd;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df) {
+        const int d = 16 * df + 4 * lc;
+        if (d + 3 < hd) {
+          typename Vec4<T>::type o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(ot[df][e] * inv);
+          *reinterpret_cast<typename Vec4<T>::type*>(crow + d) = o;
+        }
+      }
+    }
+  }
+}
+
+// frames [n][3][img][img] (f32 or f16) -> patches [n * np * np][kpad] in the operand dtype, k = (c * ps + i) * ps + j, zeros past 3 ps^2
+template <typename TI, typename T>
+__global__ void __launch_bounds__(256) vit_im2col_kernel(const TI* x, T* out, long long total, int img, int ps, int np, int kpad) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % kpad);
+  const long long patch = idx / kpad;
+  float v = 0.f;
+  if (k < 3 * ps * ps) {
+    const int c = k / (ps * ps), r = k - c * ps * ps, i = r / ps, j = r - i * ps;
+    const int px = (int)(patch % np), py = (int)((patch / np) % np);
+    const long long f = patch / (np * np);
+    v = (float)x[((f * 3 + c) * img + py * ps + i) * img + px * ps + j];
+  }
+  out[idx] = from_f32<T>(v);
+}
+
+// x[frame][0][:] = cls + pos[0]
+__global__ void __launch_bounds__(256) vit_cls_kernel(float* x, const float* cls, const float* pos, int frames, int S, int D) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)frames * D) return;
+  const int c = (int)(idx % D);
+  x[(idx / D) * S * D + c] = cls[c] + pos[c];
+}
+
+// dst (operand dtype) [rows_out][cols_out] <- src [*][cols_in]: row r takes source row map(r) (or zeros), columns past cols_in zero.
+// mode 0: identity rows (column padding only); mode 1: QKV regroup, r = (s * heads + h) * 96 + d <- s * heads * hd + h * hd + d for d < hd
+template <typename TI, typename T>
+__global__ void __launch_bounds__(256) vit_pack_kernel(const TI* src, T* dst, long long total, int cols_in, int cols_out, int mode, int heads, int hd) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cols_out);
+  const long long r = idx / cols_out;
+  long long sr = r;
+  if (mode == 1) {
+    const int d = (int)(r % HD_PAD);
+    const long long sh = r / HD_PAD;
+    sr = d < hd ? sh * hd + d : -1;
+  }
+  dst[idx] = from_f32<T>(sr >= 0 && c < cols_in ? (float)src[sr * cols_in + c] : 0.f);
+}
+
+template <typename TI>
+int pack_to(const void* src, void* dst, int op, long long rows_out, int cols_in, int cols_out, int mode, int heads, int hd, hipStream_t st) {
+  const long long total = rows_out * cols_out;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (op == OP_F16) hipLaunchKernelGGL((vit_pack_kernel<TI, f16>), grid, block, 0, st, (const TI*)src, (f16*)dst, total, cols_in, cols_out, mode, heads, hd);
+  else hipLaunchKernelGGL((vit_pack_kernel<TI, bf16>), grid, block, 0, st, (const TI*)src, (bf16*)dst, total, cols_in, cols_out, mode, heads, hd);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+struct VitLayer {
+  float *n1g, *n1b, *n2g, *n2b, *bqkv, *bproj, *bfc1, *bfc2;
+  void *wqkv, *wproj, *wfc1, *wfc2;
+};
+
+}  // namespace
+
+struct mra_vit {
+  mra_vit_cfg cfg;
+  int device = 0;
+  int S = 0, np = 0, kpad = 0, nqkv = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::map<std::string, int> loaded;   // name -> 1 once loaded
+  float *cls = nullptr, *pos = nullptr, *bpatch = nullptr;
+  void* wpatch = nullptr;
+  std::vector<VitLayer> layers;
+  int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
+};
+
+namespace {
+
+size_t vit_layout(mra_vit* h, char* base) {
+  const mra_vit_cfg& c = h->cfg;
+  const size_t D = c.dim, I = c.mlp;
+  Carver cv(base);
+  h->cls = cv.take<float>(D);
+  h->pos = cv.take<float>((size_t)h->S * D);
+  h->wpatch = cv.take<char>(D * h->kpad, 2);
+  h->bpatch = cv.take<float>(D);
+  h->layers.assign(c.depth, VitLayer{});
+  for (auto& L : h->layers) {
+    L.n1g = cv.take<float>(D); L.n1b = cv.take<float>(D); L.n2g = cv.take<float>(D); L.n2b = cv.take<float>(D);
+    L.wqkv = cv.take<char>((size_t)h->nqkv * D, 2); L.bqkv = cv.take<float>(h->nqkv);
+    L.wproj = cv.take<char>(D * D, 2); L.bproj = cv.take<float>(D);
+    L.wfc1 = cv.take<char>(I * D, 2); L.bfc1 = cv.take<float>(I);
+    L.wfc2 = cv.take<char>(D * I, 2); L.bfc2 = cv.take<float>(D);
+  }
+  return cv.off;
+}
+
+int copy_f32(const void* src, int dtype, float* dst, long long n, hipStream_t st) {
+  return launch_convert(src, dtype, dst, MRA_F32, n, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+void mra_vit_cfg_default(mra_vit_cfg* c) {
+  c->dim = 1408; c->heads = 16; c->mlp = 6144; c->depth = 39; c->patch = 14; c->img = 224; c->ln_eps = 1e-6f; c->op_dtype = MRA_F16;
+}
+
+int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
+  if (!cfg || !out) return fail(MRA_EINVAL, "null argument");
+  const mra_vit_cfg& c = *cfg;
+  if (c.dim <= 0 || c.dim % 176 || c.dim % 64) return fail(MRA_EINVAL, "dim must be a multiple of 176 and of 64 (1408)");
+  if (c.heads <= 0 || c.dim % c.heads || c.dim / c.heads > HD_PAD || (c.dim / c.heads) % 8) return fail(MRA_EINVAL, "head dimension must be a multiple of 8, <= 96");
+  if ((3 * c.heads * HD_PAD) % 256 || c.mlp <= 0 || c.mlp % 256) return fail(MRA_EINVAL, "3 * heads * 96 and mlp must be multiples of 256");
+  if (c.patch <= 0 || c.img <= 0 || c.img % c.patch || c.depth <= 0) return fail(MRA_EINVAL, "bad patch / image size / depth");
+  if (c.op_dtype != MRA_F16 && c.op_dtype != MRA_BF16) return fail(MRA_EINVAL, "op_dtype must be MRA_F16 or MRA_BF16");
+  mra_vit* h = new mra_vit();
+  h->cfg = c;
+  h->np = c.img / c.patch;
+  h->S = h->np * h->np + 1;
+  if (h->S > KS_PAD) { delete h; return fail(MRA_EINVAL, "more than 288 tokens per frame are not supported"); }
+  h->kpad = (3 * c.patch * c.patch + 63) / 64 * 64;
+  h->nqkv = 3 * c.heads * HD_PAD;
+  HIP_TRY(hipGetDevice(&h->device));
+  h->arena_bytes = vit_layout(h, nullptr);
+  const hipError_t e = hipMalloc((void**)&h->arena, h->arena_bytes);
+  if (e != hipSuccess) { delete h; return fail(MRA_ENOMEM, std::string("hipMalloc of the ViT parameter arena: ") + hipGetErrorString(e)); }
+  vit_layout(h, h->arena);
+  HIP_TRY(hipMemsetAsync(h->arena, 0, h->arena_bytes, 0));   // the key-bias third of bqkv and all padding stay zero
+  *out = h;
+  return MRA_OK;
+}
+
+void mra_vit_destroy(mra_vit* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+
+int mra_vit_load(mra_vit* h, const char* name, const void* src, int32_t dtype, const int64_t* shape, int32_t ndim, void* stream_) {
+  if (!h || !name || !src || (ndim > 0 && !shape)) return fail(MRA_EINVAL, "null argument");
+  if (dtype < MRA_F32 || dtype > MRA_BF16) return fail(MRA_EINVAL, "bad dtype");
+  const mra_vit_cfg& c = h->cfg;
+  const long long D = c.dim, I = c.mlp, hd = c.dim / c.heads;
+  long long numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= shape[i];
+  hipStream_t st = as_stream(stream_);
+  const std::string key(name);
+  auto expect = [&](long long n) { return numel == n ? 0 : fail(MRA_EINVAL, "parameter " + key + ": expected " + std::to_string(n) + " elements, got " + std::to_string(numel)); };
+  auto pack = [&](void* dst, long long rows_out, int cols_in, int cols_out, int mode) {
+    switch (dtype) {
+      case MRA_F32: return pack_to<float>(src, dst, h->op(), rows_out, cols_in, cols_out, mode, c.heads, (int)hd, st);
+      case MRA_F16: return pack_to<f16>(src, dst, h->op(), rows_out, cols_in, cols_out, mode, c.heads, (int)hd, st);
+      default: return pack_to<bf16>(src, dst, h->op(), rows_out, cols_in, cols_out, mode, c.heads, (int)hd, st);
+    }
+  };
+  int rc = 0;
+  if (key == "cls_token") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, h->cls, D, st); }
+  else if (key == "pos_embed") { if ((rc = expect((long long)h->S * D))) return rc; rc = copy_f32(src, dtype, h->pos, (long long)h->S * D, st); }
+  else if (key == "patch_embed.weight") { if ((rc = expect(D * 3 * c.patch * c.patch))) return rc; rc = pack(h->wpatch, D, 3 * c.patch * c.patch, h->kpad, 0); }
+  else if (key == "patch_embed.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, h->bpatch, D, st); }
+  else if (key.rfind("blocks.", 0) == 0) {
+    const size_t dot = key.find('.', 7);
+    if (dot == std::string::npos) return fail(MRA_ENAME, "unknown parameter name: " + key);
+    const int li = atoi(key.substr(7, dot - 7).c_str());
+    if (li < 0 || li >= c.depth) return fail(MRA_ENAME, "layer index out of range: " + key);
+    VitLayer& L = h->layers[li];
+    const std::string sub = key.substr(dot + 1);
+    if (sub == "norm1.weight") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n1g, D, st); }
+    else if (sub == "norm1.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n1b, D, st); }
+    else if (sub == "norm2.weight") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n2g, D, st); }
+    else if (sub == "norm2.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n2b, D, st); }
+    else if (sub == "attn.qkv.weight") { if ((rc = expect(3 * D * D))) return rc; rc = pack(L.wqkv, h->nqkv, (int)D, (int)D, 1); }
+    else if (sub == "attn.q_bias" || sub == "attn.v_bias") {
+      if ((rc = expect(D))) return rc;
+      // [heads][hd] -> the q (or v) third of the padded bias [3][heads][96], as f32: one padded row-set of width 1
+      float* dst = L.bqkv + (sub == "attn.q_bias" ? 0 : 2) * c.heads * HD_PAD;
+      for (int hh = 0; hh < c.heads && !rc; ++hh)
+        rc = launch_convert((const char*)src + (size_t)hh * hd * (dtype == MRA_F32 ? 4 : 2), dtype, dst + hh * HD_PAD, MRA_F32, hd, st);
+    }
+    else if (sub == "attn.proj.weight") { if ((rc = expect(D * D))) return rc; rc = pack(L.wproj, D, (int)D, (int)D, 0); }
+    else if (sub == "attn.proj.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.bproj, D, st); }
+    else if (sub == "fc1.weight") { if ((rc = expect(I * D))) return rc; rc = pack(L.wfc1, I, (int)D, (int)D, 0); }
+    else if (sub == "fc1.bias") { if ((rc = expect(I))) return rc; rc = copy_f32(src, dtype, L.bfc1, I, st); }
+    else if (sub == "fc2.weight") { if ((rc = expect(D * I))) return rc; rc = pack(L.wfc2, D, (int)I, (int)I, 0); }
+    else if (sub == "fc2.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.bfc2, D, st); }
+    else return fail(MRA_ENAME, "unknown parameter name: " + key);
+  } else return fail(MRA_ENAME, "unknown parameter name: " + key);
+  if (rc) return chk(rc, "vit load");
+  h->loaded[key] = 1;
+  return MRA_OK;
+}
+
+int mra_vit_missing(mra_vit* h) {
+  if (!h) return -1;
+  return 4 + 13 * h->cfg.depth - (int)h->loaded.size();
+}
+
+size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames) {
+  if (!h || frames <= 0) return 0;
+  const size_t M = (size_t)frames * h->S;
+  const size_t wide = std::max<size_t>(std::max<size_t>(h->nqkv, h->cfg.mlp), h->kpad);
+  return align_up(M * h->cfg.dim * 2) + align_up(M * wide * 2);
+}
+
+int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (n < 0) return fail(MRA_EINVAL, "negative frame count");
+  if (n == 0) return MRA_OK;
+  if (!frames || !out || !workspace) return fail(MRA_EINVAL, "null argument");
+  if (dtype != MRA_F32 && dtype != MRA_F16) return fail(MRA_EINVAL, "frames must be f32 or f16");
+  if (mra_vit_missing(h) > 0) return fail(MRA_ESTATE, std::to_string(mra_vit_missing(h)) + " ViT parameters not loaded");
+  if (workspace_bytes < mra_vit_workspace_bytes(h, n)) return fail(MRA_ENOMEM, "workspace too small: need " + std::to_string(mra_vit_workspace_bytes(h, n)));
+  if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MRA_EINVAL, "workspace must be 256-byte aligned");
+  const mra_vit_cfg& c = h->cfg;
+  const int D = c.dim, I = c.mlp, S = h->S, op = h->op(), hd = D / c.heads;
+  const long long M = (long long)n * S;
+  if (M > 0x7fffffffLL / 64) return fail(MRA_EINVAL, "too many frames for one call: chunk them");
+  hipStream_t st = as_stream(stream_);
+  char* a16 = (char*)workspace;
+  char* big = a16 + align_up((size_t)M * D * 2);
+  int rc;
+  {   // patches -> x[:, 1:, :] = patch GEMM + bias + pos[1:]; x[:, 0, :] = cls + pos[0]
+    const long long total = (long long)n * h->np * h->np * h->kpad;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dtype == MRA_F32) {
+      if (op == OP_F16) hipLaunchKernelGGL((vit_im2col_kernel<float, f16>), grid, block, 0, st, (const float*)frames, (f16*)big, total, c.img, c.patch, h->np, h->kpad);
+      else hipLaunchKernelGGL((vit_im2col_kernel<float, bf16>), grid, block, 0, st, (const float*)frames, (bf16*)big, total, c.img, c.patch, h->np, h->kpad);
+    } else {
+      if (op == OP_F16) hipLaunchKernelGGL((vit_im2col_kernel<f16, f16>), grid, block, 0, st, (const f16*)frames, (f16*)big, total, c.img, c.patch, h->np, h->kpad);
+      else hipLaunchKernelGGL((vit_im2col_kernel<f16, bf16>), grid, block, 0, st, (const f16*)frames, (bf16*)big, total, c.img, c.patch, h->np, h->kpad);
+    }
+    GemmProb p{};
+    const int P2 = h->np * h->np;
+    p.A = big; p.a = plain(n * P2, h->kpad);
+    p.W = h->wpatch; p.bias = h->bpatch;
+    p.R = h->pos + D; p.r = items_view(0, P2, D);
+    p.C = out + D; p.c = items_view((long long)S * D, P2, D);
+    p.M = n * P2; p.N = D; p.K = h->kpad;
+    rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
+    if (rc) return chk(rc, "patch embedding gemm");
+    hipLaunchKernelGGL(vit_cls_kernel, dim3((unsigned)(((long long)n * D + 255) / 256)), dim3(256), 0, st, out, h->cls, h->pos, n, S, D);
+  }
+  const size_t attn_lds = 2 * KS_PAD * KV_PITCH + 4 * 16 * P_PITCH;
+  static unsigned long long attr_done = 0;
+  if (!(attr_done >> (h->device & 63) & 1)) {
+    if (hipFuncSetAttribute((const void*)vit_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess)
+      return fail(MRA_EHIP, "hipFuncSetAttribute(vit_attn_kernel)");
+    attr_done |= 1ull << (h->device & 63);
+  }
+  const float sl2 = LOG2E / sqrtf((float)hd);
+  for (int li = 0; li < c.depth; ++li) {
+    const VitLayer& L = h->layers[li];
+    rc = launch_modality_ln(out, 0, nullptr, n, S, D, L.n1g, L.n1b, c.ln_eps, a16, op, st);
+    if (rc) return chk(rc, "vit ln1");
+    {
+      GemmProb p{};
+      p.A = a16; p.a = plain((int)M, D); p.W = L.wqkv; p.bias = L.bqkv;
+      p.C = big; p.c = plain((int)M, h->nqkv); p.M = (int)M; p.N = h->nqkv; p.K = D;
+      rc = launch_gemm(&p, 1, EPI_OP, op, st);
+      if (rc) return chk(rc, "vit qkv gemm");
+    }
+    if (op == OP_F16) hipLaunchKernelGGL(vit_attn_kernel<f16>, dim3(n * c.heads), dim3(256), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+    else hipLaunchKernelGGL(vit_attn_kernel<bf16>, dim3(n * c.heads), dim3(256), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
+    {
+      GemmProb p{};
+      p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;
+      p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
+      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = 5;
+      rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
+      if (rc) return chk(rc, "vit projection gemm");
+    }
+    rc = launch_modality_ln(out, 0, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
+    if (rc) return chk(rc, "vit ln2");
+    {
+      GemmProb p{};
+      p.A = a16; p.a = plain((int)M, D); p.W = L.wfc1; p.bias = L.bfc1;
+      p.C = big; p.c = plain((int)M, I); p.M = (int)M; p.N = I; p.K = D;
+      rc = launch_gemm(&p, 1, EPI_GELU_OP, op, st);
+      if (rc) return chk(rc, "vit fc1 gemm");
+    }
+    {
+      GemmProb p{};
+      p.A = big; p.a = plain((int)M, I); p.W = L.wfc2; p.bias = L.bfc2;
+      p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
+      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = 5;
+      rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
+      if (rc) return chk(rc, "vit fc2 gemm");
+    }
+  }
+  return hipGetLastError() == hipSuccess ? MRA_OK : fail(MRA_EHIP, "vit forward launch");
+}
+
+double mra_vit_flops(mra_vit* h, int32_t frames) {
+  if (!h) return 0.0;
+  const double n = h->S, d = h->cfg.dim, I = h->cfg.mlp;
+  const double per_block = 2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 4 * n * d * I;
+  return frames * (h->cfg.depth * per_block + 2.0 * (n - 1) * 3 * h->cfg.patch * h->cfg.patch * d);
+}
+
+}  // extern "C"

@@ -132,7 +132,92 @@ class EvaViTg(nn.Module):
         return float(len(self.blocks) * per_block + 2 * (n - 1) * 3 * 14 * 14 * d)
 
 
-def create_eva_vit_g(img_size=224, drop_path_rate=0.0, use_checkpoint=False, precision="fp16") -> EvaViTg:
-    """Same call shape as LAVIS' factory (the reference passes exactly these four, ``:660-662``)."""
-    m = EvaViTg(img_size=img_size)
+class HipEvaViTg(EvaViTg):
+    """The same encoder on the HIP extension (``mra_vit_*``, ``mraudio_amd/csrc/vit.hip``): this module is the parameter
+    container (state_dict keys unchanged); ``forward`` runs ALL given frames as one batched pass of hand-written gfx950
+    kernels -- the four GEMMs per block on the loader-wave MFMA kernels with bias / GELU / residual fused, a 96-padded
+    attention core, fp32 residual stream -- and returns ``[n, 257, 1408]`` fp32.  No CPU path."""
+
+    def __init__(self, *args, op_dtype: torch.dtype = torch.float16, device=None, **kw):
+        super().__init__(*args, **kw)
+        import ctypes as C
+
+        from .. import _lib
+        self._lib, self._C = _lib, C
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._handle = C.c_void_p()
+        blk = self.blocks[0]
+        cfg = _lib.mra_vit_cfg(self.num_features, blk.attn.heads, blk.fc1.out_features, len(self.blocks), self.patch_embed.kernel_size[0],
+                               self.patch_embed.kernel_size[0] * int(round((self.pos_embed.shape[1] - 1) ** 0.5)), 1e-6,
+                               _lib.MRA_BF16 if op_dtype == torch.bfloat16 else _lib.MRA_F16)
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.lib().mra_vit_create(C.byref(cfg), C.byref(self._handle)), "mra_vit_create")
+        self._dirty, self._ws = True, None
+        self.to(self._device)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._dirty = True
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        res = super().load_state_dict(*a, **kw)
+        self._dirty = True
+        return res
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self._lib.lib().mra_vit_destroy(self._handle)
+                self._handle = self._C.c_void_p()
+        except Exception:
+            pass
+
+    def sync_weights(self) -> None:
+        ver = sum(p._version for p in self.parameters())
+        if ver != getattr(self, "_ver", None):
+            self._ver, self._dirty = ver, True
+        if not self._dirty:
+            return
+        lib, C = self._lib, self._C
+        with torch.cuda.device(self._device):
+            for k, v in self.state_dict().items():
+                t = v.detach().to(self._device)
+                t = (t if t.dtype in (torch.float32, torch.float16, torch.bfloat16) else t.float()).contiguous()
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                lib.check(lib.lib().mra_vit_load(self._handle, k.encode(), lib.ptr(t), lib.mra_dtype(t.dtype), shape, t.dim(), lib.current_stream()),
+                          f"mra_vit_load({k})")
+        self._dirty = False
+
+    @torch.no_grad()
+    def forward(self, x):
+        lib = self._lib
+        self.sync_weights()
+        x = x.to(self._device)
+        if x.dtype not in (torch.float32, torch.float16):
+            x = x.float()
+        x = x.contiguous()
+        n = int(x.shape[0])
+        out = torch.empty(n, self.pos_embed.shape[1], self.num_features, dtype=torch.float32, device=self._device)
+        if n == 0:
+            return out
+        with torch.cuda.device(self._device):
+            nbytes = (int(lib.lib().mra_vit_workspace_bytes(self._handle, n)) + 255) // 256 * 256
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = None
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+            lib.check(lib.lib().mra_vit_forward(self._handle, lib.ptr(x), lib.mra_dtype(x.dtype), n, lib.ptr(out), lib.ptr(self._ws), self._ws.numel(),
+                                                lib.current_stream()), "mra_vit_forward")
+        return out
+
+    def flops(self, frames: int) -> float:
+        return float(self._lib.lib().mra_vit_flops(self._handle, frames))
+
+
+def create_eva_vit_g(img_size=224, drop_path_rate=0.0, use_checkpoint=False, precision="fp16", backend: str = "torch", **kw) -> EvaViTg:
+    """Same call shape as LAVIS' factory (the reference passes exactly the first four, ``:660-662``).  ``backend="hip"``
+    gives the encoder on this build's kernels (f16 MFMA operands = the reference's ``precision="fp16"``, fp32 residual)."""
+    if backend == "hip":
+        return HipEvaViTg(img_size=img_size, op_dtype=torch.float16 if precision == "fp16" else torch.bfloat16, **kw)
+    m = EvaViTg(img_size=img_size, **kw)
     return m.half() if precision == "fp16" else m
