@@ -71,7 +71,8 @@ __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int
 }
 
 // lane owns C[m][n .. n+3]: m = column (lane & 15) of tile j, n = 4 * (lane >> 4) + reg of tile i
-template <typename T, int FN, int FM, int EPI>
+// PRE: bias and residual are already inside the accumulators (accumulators_from_residual below)
+template <typename T, int FN, int FM, int EPI, bool PRE = false>
 __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM], int n_base, int m_base, int lane) {
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   const int M = P.M;
@@ -91,13 +92,14 @@ __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM]
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       const int n = n_base + i * 16 + ln;
+      if (P.n_mask && n >= P.N) continue;   // masked tail of a ragged last column tile
       f32x4 v = acc[i][j];
-      if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n);
+      if (!PRE && P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n);
       if constexpr (EPI == EPI_GELU_OP) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
-      if constexpr (EPI == EPI_RES_F32) v += *reinterpret_cast<const f32x4*>(P.R + roff + n);
+      if constexpr (EPI == EPI_RES_F32 && !PRE) v += *reinterpret_cast<const f32x4*>(P.R + roff + n);
       if constexpr (EPI == EPI_RES_F32 || EPI == EPI_F32) {
         *reinterpret_cast<f32x4*>((float*)P.C + coff + n) = v;
       } else {
@@ -116,6 +118,29 @@ __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM]
           *reinterpret_cast<typename Vec4<T>::type*>((T*)P.C + coff + n) = o;
         }
       }
+    }
+  }
+}
+
+// EPI_RES_F32 on the big tiles: start the accumulators at bias + residual instead of zero.  The fp32 residual read (half of
+// that epilogue's traffic, 64-byte pieces of 16 rows per instruction) then happens before the K loop, hidden behind the wait
+// for the first operand tiles, and the epilogue only stores.
+template <int FN, int FM>
+__device__ __forceinline__ void accumulators_from_residual(const GemmProb& P, f32x4 (&acc)[FN][FM], int n_base, int m_base, int lane) {
+  const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = min(m_base + j * 16 + lm, P.M - 1);   // rows past M are computed on a clamped row and never stored
+    const long long roff = view_off(P.r, m);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n_base + i * 16 + ln;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (!P.n_mask || n < P.N) {
+        v = *reinterpret_cast<const f32x4*>(P.R + roff + n);
+        if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n);
+      }
+      acc[i][j] = v;
     }
   }
 }
@@ -432,10 +457,14 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
                        (8 * (lane >> 4) + ((lane & 15) >> 2)) * (TN * 2) + (lane & 3) * 8;
   static_assert(!WKM || WGN == 1, "K-major weights: one column of compute waves");
   f32x4 acc[FN][FM];
+  if constexpr (EPI == EPI_RES_F32) {
+    accumulators_from_residual<FN, FM>(P, acc, n0 + wn0, m0 + wm0, lane);
+  } else {
 #pragma unroll
-  for (int i = 0; i < FN; ++i)
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();
@@ -491,7 +520,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
-    epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
+    epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
 }
 
@@ -653,8 +682,6 @@ int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (wei
   if (epi == EPI_F32) return launch_k(gemm_ws_kernel<T, EPI_F32, false, 176, 384, 8, true>, a, 768, lds, stream);
   if (epi == EPI_SOFTPART) return launch_k(gemm_ws_kernel<T, EPI_SOFTPART, false, 176, 384, 8, true>, a, 768, lds, stream);
   if (epi == EPI_OP) return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true>, a, 768, lds, stream);
-  // N = 1408 = 8 x 176 projections of the ViT blocks (vit.hip): the 176 weight rows are shared by every row tile -> default cache policy
-  if (epi == EPI_RES_F32) return launch_k(gemm_ws_kernel<T, EPI_RES_F32, false, 176, 384, 8, false>, a, 768, lds, stream);
   return -2;
 }
 
@@ -715,7 +742,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
     long long tiles = 0;
     bool ok = true;
     for (int g = 0; g < ngroups; ++g) {
-      if (probs[g].N % t && !probs[g].n_ragged) ok = false;
+      if (probs[g].N % t && !probs[g].n_ragged && !probs[g].n_mask) ok = false;
       tiles += (long long)((probs[g].M + t - 1) / t) * ((probs[g].N + t - 1) / t) * (probs[g].batch > 1 ? probs[g].batch : 1);
     }
     if (!ok) continue;
@@ -740,7 +767,8 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     a.p[g] = probs[g];
     GemmProb& p = a.p[g];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
-    if (p.K % 64 || (p.N % t && !p.n_ragged)) return -1;
+    if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask)) return -1;
+    if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32) || (p.N & 3) || p.n_ragged)) return -1;
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;

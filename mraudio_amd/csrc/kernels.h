@@ -48,6 +48,9 @@ struct GemmProb {
   // n_ragged: N need not be a multiple of the tile; weight rows past N - 1 are read from row N - 1 and their
   // output columns are written anyway, so C rows must hold ceil(N / tile) * tile columns and bias must be null.
   int n_ragged;
+  // n_mask (EPI_RES_F32 / EPI_F32): N need not be a multiple of the tile either, but output columns past N - 1 are simply not
+  // stored (bias and residual are not read there): C keeps its plain [M][N] rows.  N % 4 == 0.
+  int n_mask;
   // w_ld > 0 (176 x 384 loader-wave tile, EPI_OP only): W is given K-major, W[k][n] at W + k * w_ld + n (a plain [K][N] row-major
   // matrix, e.g. the encoder tokens themselves for P . enc); rows k >= k_rows are read from row k_rows - 1 (the A operand
   // is zero there).  The kernel stages [64 k][176 n] tiles and takes its fragments with ds_read_b64_tr_b16.

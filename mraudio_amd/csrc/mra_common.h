@@ -84,7 +84,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 everywhere: far below the f16 / bf16 rounding of every consumer):
+// one rcp, one exp2 and five fmas instead of the device library's branchy erff, which cost the fc1 GEMM of the ViT blocks
+// a third of its time (1.34 ms against 1.00 ms for the same tile with a plain epilogue, 256 frames)
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(r, x);
+}
 // exact (erf) GELU, as BERT's "gelu" (HF ACT2FN["gelu"], reference path uses hidden_act = "gelu")
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 }  // namespace mra

@@ -9,8 +9,9 @@
 //   im2col -> patch GEMM (+ bias + position embedding in the epilogue) -> [CLS] rows
 //   39 x { LN -> QKV GEMM -> attention core -> projection GEMM + residual -> LN -> fc1 GEMM + GELU -> fc2 GEMM + residual }
 // 97 % of the flops are the four GEMMs per block at M = frames x 257 rows: the loader-wave kernels of gemm.hip (256 x 256 for
-// N = 4608 / 6144, 176 x 384 for N = 1408 = 8 x 176) with bias / GELU / residual fused into their epilogues.  The fp32
-// residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
+// all four, the N = 1408 ones with a masked last column tile) with bias / GELU / residual fused: the residual GEMMs START
+// their accumulators at bias + residual, so their epilogue only stores.  The fp32 residual stream is updated in place and
+// IS the output; LayerNorms write the f16 operand of the next GEMM.
 // Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
 // per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
 // MFMA steps; the zero columns add nothing to any dot product.
@@ -29,43 +30,59 @@ namespace {
 constexpr int HD_PAD = 96;      // padded head dimension
 constexpr int KS_PAD = 288;     // keys padded to 9 MFMA K steps of 32 (257 valid)
 constexpr int KV_PITCH = 208;   // LDS row pitch of K / V tiles: 13 sixteen-byte slots -> conflict-free ds_read_b128 over 16 rows
-constexpr int P_PITCH = 592;    // LDS row pitch of a wave's P tile: 37 slots
 constexpr float LOG2E = 1.4426950408889634f;
 
 // ---------------------------------------------------------------------------------------------------------
-// attention core: one workgroup per (frame, head), K and V of the head staged once in LDS, each wave takes 16-query
-// blocks: S^T = K Q^T (keys on the MFMA row index), softmax over the lane's key column group, P through a wave-private
-// LDS tile into the B operand of O^T = V^T P^T (V^T by transposed LDS reads).
+// attention core: one workgroup of nine waves per (frame, head); K and V of the head are staged once in LDS and each wave
+// takes 16-query blocks (17 blocks: at most two per wave).  S^T = K Q^T puts the keys on the MFMA row index, so a lane
+// holds, for its query, keys 16 i + 4 c + 0..3 of every 16-key fragment i (c = lane >> 4): the softmax is a reduction over
+// the lane's own registers plus two lane swaps, and -- since the order of the contraction index inside an MFMA is free as
+// long as both operands agree -- fragments 2 ks and 2 ks + 1 together ARE the B operand of K step ks of O^T = V^T P^T
+// (keys 32 ks + 4 c + 0..3 and 32 ks + 16 + 4 c + 0..3): P never leaves the registers.  V^T takes the same key order from
+// two transposed LDS reads (ds_read_b64_tr_b16) of V [key][d].
 // ---------------------------------------------------------------------------------------------------------
+constexpr int ATT_WAVES = 9;
 template <typename T>
-__global__ void __launch_bounds__(256) vit_attn_kernel(const T* qkv, T* ctx, int S, int heads, int hd, float sl2) {
+__global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, T* ctx, int S, int heads, int hd, float sl2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + KS_PAD * KV_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* Pw = smem + 2 * KS_PAD * KV_PITCH + wave * 16 * P_PITCH;
   const int frame = blockIdx.x / heads, head = blockIdx.x - frame * heads;
   const int ld = 3 * heads * HD_PAD;
   const T* base = qkv + (long long)frame * S * ld + head * HD_PAD;
   using V8 = typename Vec8<T>::type;
-  // ---- K, V rows of this head -> LDS (rows past S zeroed) ----
-  for (int c = tid; c < KS_PAD * 12; c += 256) {
-    const int row = c / 12, ch = c - row * 12;
-    V8 k, v;
+  // ---- K, V rows of this head -> LDS (rows past S zeroed).  Every load is issued before the first LDS write and none sits
+  // under a lane-dependent branch (a clamped row is loaded and zeroed instead): one round trip, not one per chunk.
+  {
+    constexpr int NCH = (KS_PAD * 12 + ATT_WAVES * 64 - 1) / (ATT_WAVES * 64);
+    V8 kr[NCH], vr[NCH];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { k[e] = from_f32<T>(0.f); v[e] = k[e]; }
-    if (row < S) {
-      const T* p = base + (long long)row * ld + ch * 8;
-      k = *reinterpret_cast<const V8*>(p + heads * HD_PAD);
-      v = *reinterpret_cast<const V8*>(p + 2 * heads * HD_PAD);
+    for (int u = 0; u < NCH; ++u) {
+      const int c = min(tid + u * ATT_WAVES * 64, KS_PAD * 12 - 1);
+      const int row = c / 12, ch = c - row * 12;
+      const T* p = base + (long long)min(row, S - 1) * ld + ch * 8;
+      kr[u] = *reinterpret_cast<const V8*>(p + heads * HD_PAD);
+      vr[u] = *reinterpret_cast<const V8*>(p + 2 * heads * HD_PAD);
     }
-    *reinterpret_cast<V8*>(Ks + row * KV_PITCH + ch * 16) = k;
-    *reinterpret_cast<V8*>(Vs + row * KV_PITCH + ch * 16) = v;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int c = tid + u * ATT_WAVES * 64;
+      const int row = c / 12, ch = c - row * 12;
+      if (row >= S) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[u][e] = from_f32<T>(0.f); vr[u][e] = kr[u][e]; }
+      }
+      if (c < KS_PAD * 12) {
+        *reinterpret_cast<V8*>(Ks + row * KV_PITCH + ch * 16) = kr[u];
+        *reinterpret_cast<V8*>(Vs + row * KV_PITCH + ch * 16) = vr[u];
+      }
+    }
   }
   __syncthreads();
   const int lm = lane & 15, lc = lane >> 4;
   const int nblocks = (S + 15) >> 4;
-  for (int qb = wave; qb < nblocks; qb += 4) {
+  for (int qb = wave; qb < nblocks; qb += ATT_WAVES) {
     const int q0 = qb * 16;
     // Q fragments (B operand): lane (query lm, chunk lc) holds Q[q0 + lm][32 ks + 8 lc .. + 7]
     V8 qf[3];
@@ -83,6 +100,8 @@ __global__ void __launch_bounds__(256) vit_attn_kernel(const T* qkv, T* ctx, int
       for (int ks = 0; ks < 3; ++ks) {
         const V8 kf = *reinterpret_cast<const V8*>(Ks + (16 * i + lm) * KV_PITCH + (4 * ks + lc) * 16);
         a = mfma16<T>(kf, qf[ks], a);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -94,39 +113,33 @@ __global__ void __launch_bounds__(256) vit_attn_kernel(const T* qkv, T* ctx, int
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float l = 0.f;
-#pragma unroll
-    for (int i = 0; i < KS_PAD / 16; ++i) {
-      typename Vec4<T>::type o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float p = __builtin_amdgcn_exp2f(sc[i][e] - mx);   // masked keys: exp2(-huge) = 0
-        o[e] = from_f32<T>(p);
-        l += (float)o[e];
-      }
-      *reinterpret_cast<typename Vec4<T>::type*>(Pw + lm * P_PITCH + (16 * i + 4 * lc) * 2) = o;
-    }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the P tile is read back by other lanes of this wave
-    __builtin_amdgcn_wave_barrier();
     // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]
     f32x4 ot[HD_PAD / 16];
 #pragma unroll
     for (int df = 0; df < HD_PAD / 16; ++df) ot[df] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS_PAD / 32; ++ks) {
-      const V8 pf = *reinterpret_cast<const V8*>(Pw + lm * P_PITCH + (32 * ks + 8 * lc) * 2);
-      // V^T fragment of d block df: two transposed 4 x 16 blocks (keys 32 ks + 8 lc + 0..3 and + 4..7)
-      const char* vb = Vs + (32 * ks + 8 * lc + (lm >> 2)) * KV_PITCH + (lane & 3) * 8;
+      V8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = from_f32<T>(__builtin_amdgcn_exp2f(sc[2 * ks][e] - mx));          // masked keys: exp2(-huge) = 0
+        pf[4 + e] = from_f32<T>(__builtin_amdgcn_exp2f(sc[2 * ks + 1][e] - mx));
+        l += (float)pf[e] + (float)pf[4 + e];
+      }
+      // V^T fragment of d block df in the same key order: transposed 4 x 16 blocks at keys 32 ks + 4 lc and 32 ks + 16 + 4 lc
+      const char* vb = Vs + (32 * ks + 4 * lc + (lm >> 2)) * KV_PITCH + (lane & 3) * 8;
 #pragma unroll
       for (int df = 0; df < HD_PAD / 16; ++df) {
-        const i16x4 c0 = lds_read_tr4(vb + df * 32), c1 = lds_read_tr4(vb + df * 32 + 4 * KV_PITCH);
+        const i16x4 c0 = lds_read_tr4(vb + df * 32), c1 = lds_read_tr4(vb + df * 32 + 16 * KV_PITCH);
         i16x8 v;
         v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
         ot[df] = mfma16<T>(__builtin_bit_cast(V8, v), pf, ot[df]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two transposed reads, one MFMA: keep the reads one fragment
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ahead instead of hoisting all 108 (the allocator then spills)
       }
     }
-    __builtin_amdgcn_wave_barrier();   // the next block's P writes must not overtake these reads
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     if (q0 + lm < S) {
       T* crow = ctx + ((long long)frame * S + q0 + lm) * (heads * hd) + head * hd;
@@ -212,6 +225,8 @@ struct mra_vit {
   float *cls = nullptr, *pos = nullptr, *bpatch = nullptr;
   void* wpatch = nullptr;
   std::vector<VitLayer> layers;
+  int proj_tile = 3;   // GemmProb::tile_cfg of the N = dim GEMMs: 256 x 256 with a masked last column tile (1408 = 5.5 tiles); the exact-fit
+                       // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
 };
 
@@ -383,7 +398,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
     if (rc) return chk(rc, "patch embedding gemm");
     hipLaunchKernelGGL(vit_cls_kernel, dim3((unsigned)(((long long)n * D + 255) / 256)), dim3(256), 0, st, out, h->cls, h->pos, n, S, D);
   }
-  const size_t attn_lds = 2 * KS_PAD * KV_PITCH + 4 * 16 * P_PITCH;
+  const size_t attn_lds = 2 * KS_PAD * KV_PITCH;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> (h->device & 63) & 1)) {
     if (hipFuncSetAttribute((const void*)vit_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
@@ -403,13 +418,13 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
       rc = launch_gemm(&p, 1, EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
-    if (op == OP_F16) hipLaunchKernelGGL(vit_attn_kernel<f16>, dim3(n * c.heads), dim3(256), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
-    else hipLaunchKernelGGL(vit_attn_kernel<bf16>, dim3(n * c.heads), dim3(256), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
+    if (op == OP_F16) hipLaunchKernelGGL(vit_attn_kernel<f16>, dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+    else hipLaunchKernelGGL(vit_attn_kernel<bf16>, dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
     {
       GemmProb p{};
       p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;
       p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
-      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = 5;
+      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
       rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit projection gemm");
     }
@@ -426,7 +441,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
       GemmProb p{};
       p.A = big; p.a = plain((int)M, I); p.W = L.wfc2; p.bias = L.bfc2;
       p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
-      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = 5;
+      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
       rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit fc2 gemm");
     }

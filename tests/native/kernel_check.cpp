@@ -338,6 +338,37 @@ static void test_gemm_kmajor(int op, int M, int N, int K, int k_rows, int batch)
   report(name, worst, 3e-3);
 }
 
+// n_mask: N not a multiple of the tile, plain [M][N] output rows; columns past N are neither read (bias, residual) nor stored
+static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
+  gemm_force_config(-1);
+  std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K);
+  for (auto& v : A) v = to_op(frand(), op);
+  for (auto& v : W) v = to_op(frand(0.05f), op);
+  std::vector<float> bias(N), R((size_t)M * N), C0((size_t)M * N + 512, 7.5f);
+  for (auto& v : bias) v = frand(0.5f);
+  for (auto& v : R) v = frand();
+  Dev<uint16_t> dA(A), dW(W);
+  Dev<float> dB(bias), dR(R), dC(C0);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = dB.p; p.R = dR.p; p.r = RowView{0, M, N};
+  p.C = dC.p; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.n_mask = 1; p.tile_cfg = cfg + 1;
+  const int rc = launch_gemm(&p, 1, epi, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> c = dC.get();
+  double worst = rc ? 1e30 : 0;
+  for (int m = 0; m < M && !rc; ++m)
+    for (int n = 0; n < N; ++n) {
+      double acc = bias[n] + (epi == EPI_RES_F32 ? R[(size_t)m * N + n] : 0.0);
+      for (int k = 0; k < K; ++k) acc += (double)from_op(A[(size_t)m * K + k], op) * from_op(W[(size_t)n * K + k], op);
+      worst = std::max(worst, fabs(c[(size_t)m * N + n] - acc) / (1 + fabs(acc)));
+    }
+  for (size_t i = (size_t)M * N; i < c.size(); ++i) if (c[i] != 7.5f) worst = 1e30;   // nothing may be written past the matrix
+  char name[128];
+  snprintf(name, sizeof(name), "gemm masked-N cfg%d epi%d %s M%d N%d K%d", cfg, epi, op == OP_F16 ? "f16" : "bf16", M, N, K);
+  report(name, worst, 2e-4);
+}
+
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
   gemm_force_config(-1);
@@ -427,7 +458,9 @@ static void test_fold_stream(int items, int kv, int E, float gain) {
     }
   char name[160];
   snprintf(name, sizeof(name), "fold stream items%d kv%d E%d gain%.0f (max row probability %.3f)", items, kv, E, gain, peak);
-  report(name, worst, 6e-3);     // f16 P~ (11 bits) and f16 output against |U| ~ 0.05 .. 1
+  // f16 P~ (11 bits) and f16 output against |U| ~ 0.05 .. 1; with peaked rows the f16 rounding of Q' (scores of magnitude 10 .. 60)
+  // moves probability between near-tied keys: the same amplification as in tests/test_gpu_headline.py, not a kernel property
+  report(name, worst, gain > 1.5f ? 2e-2 : 6e-3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,6 +936,9 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  test_gemm_masked(2, EPI_RES_F32, OP_F16, 700, 352, 128);   // N = 1.4 column tiles of 256, the tail is neither read nor stored
+  test_gemm_masked(2, EPI_F32, OP_F16, 300, 1408, 192);
+  test_gemm_masked(1, EPI_RES_F32, OP_BF16, 200, 200, 64);
   test_gemm_batched(1, EPI_F32, OP_F16, 96, 300, 192, 3, true);     // scores: M = 3 x 32 rows, N = kv ragged
   test_gemm_batched(1, EPI_OP, OP_F16, 96, 256, 320, 3, false);     // P . enc^T
   test_gemm_batched(0, EPI_OP, OP_F16, 70, 128, 64, 4, false);      // per-head projections, K = 64

@@ -1,0 +1,35 @@
+"""Times the EVA ViT-g encode stage (row A1 / N4) on the HIP extension; prints one JSON line.  For rocprofv3:
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_vit -- python3 tools/bench_vit.py --frames 256 --reps 2"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mraudio_amd.models.eva_vit import create_eva_vit_g  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=256)
+ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--backend", default="hip")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+if a.backend == "hip":
+    vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev).eval().init_seeded_(0)
+else:
+    with torch.device(dev):
+        vit = create_eva_vit_g(224, 0, False, "fp16").eval()
+x = torch.randn(a.frames, 3, 224, 224, device=dev, dtype=torch.float16)
+with torch.no_grad():
+    vit(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        vit(x)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / a.reps
+fl = vit.flops_per_frame() * a.frames
+print(json.dumps({"backend": a.backend, "frames": a.frames, "ms": round(t * 1e3, 2), "tflops": round(fl / t / 1e12, 1), "frames_per_s": round(a.frames / t, 1)}))
