@@ -100,8 +100,6 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
       for (int ks = 0; ks < 3; ++ks) {
         const V8 kf = *reinterpret_cast<const V8*>(Ks + (16 * i + lm) * KV_PITCH + (4 * ks + lc) * 16);
         a = mfma16<T>(kf, qf[ks], a);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -109,6 +107,15 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
         mx = fmaxf(mx, a[e]);
       }
       sc[i] = a;
+    }
+    // Scheduling of the 54 K-fragment reads against the 54 MFMAs: six reads run ahead, then one read per MFMA.  Left alone
+    // the scheduler hoists every read above the first MFMA and the allocator spills (644 bytes of scratch per lane, 0.96 ms per
+    // layer); strictly one read per MFMA exposes the LDS latency on every MFMA (0.37 ms).
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 3 * KS_PAD / 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -134,9 +141,13 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
         i16x8 v;
         v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
         ot[df] = mfma16<T>(__builtin_bit_cast(V8, v), pf, ot[df]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two transposed reads, one MFMA: keep the reads one fragment
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ahead instead of hoisting all 108 (the allocator then spills)
       }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // same for the 108 transposed V reads: four fragments ahead
+#pragma unroll
+    for (int i = 0; i < (HD_PAD / 16) * (KS_PAD / 32); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
