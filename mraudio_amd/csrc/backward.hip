@@ -112,10 +112,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // GELU
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_grad(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  return cdf + u * 0.39894228040143267794f * __expf(-0.5f * u * u);
-}
+__device__ __forceinline__ float gelu_grad(float u) { return gelu_erf_grad(u); }
 
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) gelu_kernel(const T* u, const T* df, T* out, long long n8) {

@@ -99,6 +99,17 @@ __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM]
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
+      if constexpr (EPI == EPI_GELU_BOTH) {     // keep the pre-activation for the backward, return the activation
+        typename Vec4<T>::type u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = from_f32<T>(v[e]); v[e] = gelu_erf((float)u[e]); }
+        *reinterpret_cast<typename Vec4<T>::type*>((T*)P.aux + coff + n) = u;
+      }
+      if constexpr (EPI == EPI_GELU_BWD) {      // d(pre-activation) = d(activation) * gelu'(pre-activation)
+        const typename Vec4<T>::type u = *reinterpret_cast<const typename Vec4<T>::type*>((const T*)P.aux + coff + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad((float)u[e]);
+      }
       if constexpr (EPI == EPI_RES_F32 && !PRE) v += *reinterpret_cast<const f32x4*>(P.R + roff + n);
       if constexpr (EPI == EPI_RES_F32 || EPI == EPI_F32) {
         *reinterpret_cast<f32x4*>((float*)P.C + coff + n) = v;
@@ -646,6 +657,8 @@ int launch_k(KFN kfn, const GemmArgs& a, int threads, size_t lds, hipStream_t st
     case EPI_RES_F32: { constexpr int E = EPI_RES_F32; return KERNEL_EXPR; } \
     case EPI_F32: { constexpr int E = EPI_F32; return KERNEL_EXPR; }         \
     case EPI_KV: { constexpr int E = EPI_KV; return KERNEL_EXPR; }           \
+    case EPI_GELU_BOTH: { constexpr int E = EPI_GELU_BOTH; return KERNEL_EXPR; } \
+    case EPI_GELU_BWD: { constexpr int E = EPI_GELU_BWD; return KERNEL_EXPR; }   \
     default: return -2;                                     \
   }
 
@@ -777,6 +790,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
+    if ((epi == EPI_GELU_BOTH || epi == EPI_GELU_BWD) && (!p.aux || (p.c.ld & 3) || (p.c.item_stride & 3) || p.n_ragged)) return -1;
     p.mtiles = (p.M + tm - 1) / tm;
     p.ntiles = (p.N + t - 1) / t;
     p.tile_begin = tiles;

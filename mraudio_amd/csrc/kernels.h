@@ -15,6 +15,8 @@ enum GemmEpi {
   EPI_RES_F32 = 2,  // C(f32)      = acc + bias + R
   EPI_F32 = 3,      // C(f32)      = acc + bias
   EPI_KV = 4,       // C(op dtype) head-major K/V cache, see GemmProb::kv_*
+  EPI_GELU_BOTH = 6, // training forward: aux(op dtype) = acc + bias (the pre-activation the backward needs), C(op dtype) = gelu_erf of it
+  EPI_GELU_BWD = 7,  // training backward: C(op dtype) = acc * gelu'(aux): the GELU gradient inside the data-gradient GEMM
   EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile
                     // sum go to stat_m / stat_l [row][ntiles] (176 x 384 loader-wave tile only: a wave holds whole tile rows)
 };
@@ -35,6 +37,7 @@ struct GemmProb {
   const float* bias;  // [N] or nullptr
   void* C;            // row view `c`
   const float* R;     // residual (EPI_RES_F32), row view `r`
+  void* aux;          // EPI_GELU_BOTH (written) / EPI_GELU_BWD (read): op-dtype tensor addressed like C (row view `c`)
   RowView a, c, r;
   int M, N, K;
   // EPI_KV: weight row n = (cl * 2 + kv) * hidden + head * 64 + d ; activation row m = item * kv_tokens + tok

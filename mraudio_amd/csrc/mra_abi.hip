@@ -300,6 +300,8 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (h->arena_f) (void)hipFree(h->arena_f);
   if (h->flat_segs) (void)hipFree(h->flat_segs);
   if (h->tr_jobs) (void)hipFree(h->tr_jobs);
+  for (auto& e : h->wg_ev) if (e) (void)hipEventDestroy(e);
+  if (h->wg_stream) (void)hipStreamDestroy(h->wg_stream);
   delete h;
 }
 

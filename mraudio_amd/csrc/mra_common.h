@@ -94,6 +94,10 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   return copysignf(r, x);
 }
+// d/du gelu_erf(u) = Phi(u) + u phi(u)
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+  return 0.5f * (1.0f + erf_fast(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+}
 // exact (erf) GELU, as BERT's "gelu" (HF ACT2FN["gelu"], reference path uses hidden_act = "gelu")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 

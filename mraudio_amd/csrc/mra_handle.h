@@ -103,6 +103,8 @@ struct mra_qformer {
   bool transposes_stale = true;
   mra::TrJob* tr_jobs = nullptr;   // device table of the batched transpose (built on first use)
   int n_tr_jobs = 0, n_tr_tiles = 0;
+  hipStream_t wg_stream = nullptr;                // side stream of the weight-gradient GEMMs (mra_qformer_backward)
+  hipEvent_t wg_ev[32] = {};                      // ring of fork / done events between the caller's stream and wg_stream
   size_t grad_bytes = 0;
   mra::FlatSeg* flat_segs = nullptr;  // device table behind mra_qformer_load_flat (bert.* parameters)
   int n_flat_segs = 0;

@@ -32,7 +32,7 @@ struct TrainBufs {
   char* kv16; float* part; int nsplit;
   // backward scratch
   float *dhA, *dhB, *dpre32, *dhc32, *dpre2_32;
-  char *dpre16, *dff16, *dctx16, *dqkv16, *dpre2_16, *dcctx16, *dqc16, *dkv16;
+  char *dpre16, *dpre16b, *dff16, *dctx16, *dqkv16, *dpre2_16, *dcctx16, *dqc16, *dkv16;
   size_t bytes;
 };
 
@@ -79,6 +79,7 @@ TrainBufs layout_train(const mra_qformer* h, char* base, int N, int L, int Kv) {
   t.dhc32 = cv.take<float>(N * Q * H);
   t.dpre2_32 = cv.take<float>(N * Q * H);
   t.dpre16 = cv.take<char>(N * S * H, 2);
+  t.dpre16b = cv.take<char>(N * S * H, 2);
   t.dff16 = cv.take<char>(N * S * I, 2);
   t.dctx16 = cv.take<char>(N * S * H, 2);
   t.dqkv16 = cv.take<char>(N * S * 3 * H, 2);
@@ -149,12 +150,13 @@ struct Ctx {
   mra_qformer* h;
   hipStream_t stream;
   int op;
-  // forward-kernel GEMM:  C = A W^T (+bias) (+R)
+  hipStream_t wstream;   // weight-gradient GEMMs: the handle's side stream (backward) or `stream`
+  // forward-kernel GEMM:  C = A W^T (+bias) (+R); aux: the pre-activation tensor of EPI_GELU_BOTH / EPI_GELU_BWD
   int gemm(const void* A, RowView av, const void* W, const float* bias, void* C, RowView cv, const float* R, RowView rv, int M, int N,
-           int K, int epi) const {
+           int K, int epi, void* aux = nullptr) const {
     if (M <= 0) return 0;
     GemmProb p{};
-    p.A = A; p.a = av; p.W = W; p.bias = bias; p.C = C; p.c = cv; p.R = R; p.r = rv;
+    p.A = A; p.a = av; p.W = W; p.bias = bias; p.C = C; p.c = cv; p.R = R; p.r = rv; p.aux = aux;
     p.M = M; p.N = N; p.K = K;
     return launch_gemm(&p, 1, epi, op, stream);
   }
@@ -164,7 +166,7 @@ struct Ctx {
     GemmTnArgs a{};
     a.dY = dY; a.X = X; a.dW = dW; a.yv = yv; a.xv = xv; a.y_block_stride = y_block_stride; a.x_block_stride = 64;
     a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1; a.db = db;
-    return launch_gemm_tn(a, op, stream);
+    return launch_gemm_tn(a, op, wstream);
   }
 };
 
@@ -197,6 +199,10 @@ int mra_qformer_enable_training(mra_qformer* h, void* stream) {
     layout_transposes(h, h->arena_t);
     h->transposes_stale = true;
   }
+  if (!h->wg_stream) {   // weight-gradient GEMMs run beside the data-gradient chain (mra_qformer_backward)
+    HIP_TRY(hipStreamCreateWithFlags(&h->wg_stream, hipStreamNonBlocking));
+    for (auto& e : h->wg_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   if (h->transposes_stale) return chk(refresh_transposes(h, as_stream(stream)), "weight transposes");
   return MRA_OK;
 }
@@ -217,7 +223,7 @@ int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const in
     return fail(MRA_ENOMEM, "training workspace too small or misaligned");
   hipStream_t stream = as_stream(stream_);
   const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
-  const Ctx X{h, stream, h->op()};
+  const Ctx X{h, stream, h->op(), stream};
   const int op = X.op;
   TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
   const long long SH = (long long)S * H;
@@ -264,9 +270,9 @@ int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const in
     // feed-forwards: rows [0, N*Q) of u16 / f16 are the query rows, [N*Q, N*S) the text rows
     char* u_t = b.u16 + (size_t)N * Q * I * 2;
     char* f_t = b.f16 + (size_t)N * Q * I * 2;
-    if ((rc = X.gemm(fq16, fqv, W.wiq, W.biq, b.u16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_OP))) return chk(rc, "ffn-q up");
-    if ((rc = X.gemm(b.h1_16 + t16, t_view, W.wit, W.bit, u_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_OP))) return chk(rc, "ffn-t up");
-    if ((rc = launch_gelu(b.u16, nullptr, b.f16, (long long)N * S * I, 0, op, stream))) return chk(rc, "gelu");
+    // up-projection + GELU in one epilogue: u16 keeps the pre-activation for the backward, f16 is the activation
+    if ((rc = X.gemm(fq16, fqv, W.wiq, W.biq, b.f16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_GELU_BOTH, b.u16))) return chk(rc, "ffn-q up");
+    if ((rc = X.gemm(b.h1_16 + t16, t_view, W.wit, W.bit, f_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_GELU_BOTH, u_t))) return chk(rc, "ffn-t up");
     if ((rc = X.gemm(b.f16, plain(N * Q, I), W.woq, W.boq, b.pre3, q_view, fq32, fqv, N * Q, H, I, EPI_RES_F32))) return chk(rc, "ffn-q down");
     if ((rc = X.gemm(f_t, plain(N * L, I), W.wot, W.bot, b.pre3 + t32, t_view, b.h1_32 + t32, t_view, N * L, H, I, EPI_RES_F32))) return chk(rc, "ffn-t down");
     if ((rc = launch_ln_rows(b.pre3, q_view, N * Q, H, W.lnqg, W.lnqb, c.ln_eps, nxt32, q_view, nxt16, q_view, op, stream))) return chk(rc, "ffn-q ln");
@@ -289,8 +295,18 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
   const mra_cfg& c = h->cfg;
   hipStream_t stream = as_stream(stream_);
   const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
-  const Ctx X{h, stream, h->op()};
+  if (!h->wg_stream) return fail(MRA_ESTATE, "call mra_qformer_enable_training first");
+  // Weight gradients are off the critical path (nothing in this call reads them): they run on the handle's side stream beside
+  // the data-gradient chain.  fork(): the side stream waits for everything issued on `stream` so far (the dY it is about to
+  // read); done(): an event on the side stream that `stream` waits for before it overwrites a scratch tensor those GEMMs read;
+  // the call ends with a join, so to the caller everything still happens on `stream`.
+  const Ctx X{h, stream, h->op(), h->wg_stream};   // measured: backward 10.7 -> 8.6 ms at B = 1 x T = 20, both modalities
   const int op = X.op;
+  int evi = 0;
+  auto next_event = [&]() { return h->wg_ev[evi++ % (int)(sizeof(h->wg_ev) / sizeof(h->wg_ev[0]))]; };
+  auto fork = [&]() { hipEvent_t e = next_event(); (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(h->wg_stream, e, 0); };
+  auto done = [&]() { hipEvent_t e = next_event(); (void)hipEventRecord(e, h->wg_stream); return e; };
+  hipEvent_t ffn_done = nullptr, attn_done = nullptr;   // weight gradients of the previously processed layer
   TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
   const long long SH = (long long)S * H;
   const RowView all_rows = plain(N * S, H), q_view = items_view(SH, Q, H), t_view = items_view(SH, L > 0 ? L : 1, H);
@@ -315,6 +331,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
     const char* u_t = b.u16 + (size_t)N * Q * I * 2;
     const char* f_t = b.f16 + (size_t)N * Q * I * 2;
     char* dff_t = t.dff16 + (size_t)N * Q * I * 2;
+    if (ffn_done) (void)hipStreamWaitEvent(stream, ffn_done, 0);   // dpre16 / dff16 / dpre2_16 / dqc16 are about to be rewritten
     // ---- feed-forward, query rows: out = LN(pre3), pre3 = f Woq^T + b + fq ----
     {
       LnBwdArgs a{};
@@ -323,10 +340,11 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       a.dgamma = G(p + "output_query.LayerNorm.weight"); a.dbeta = G(p + "output_query.LayerNorm.bias");
       if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-q ln bwd");
     }
+    // d(pre-activation) = (d_pre3 Woq) * gelu'(u): the GELU gradient is the data-gradient GEMM's epilogue
+    if ((rc = X.gemm(t.dpre16, qc_rows, W.woqT, nullptr, t.dff16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_GELU_BWD, b.u16))) return chk(rc, "dff-q");
+    fork();
     if ((rc = X.wgrad(t.dpre16, qc_rows, 64, b.f16, plain(N * Q, I), N * Q, H, I, G(p + "output_query.dense.weight"), G(p + "output_query.dense.bias"))))
       return chk(rc, "dWoq");
-    if ((rc = X.gemm(t.dpre16, qc_rows, W.woqT, nullptr, t.dff16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_OP))) return chk(rc, "dff-q");
-    if ((rc = launch_gelu(b.u16, t.dff16, t.dff16, (long long)N * Q * I, 1, op, stream))) return chk(rc, "gelu bwd q");
     if ((rc = X.wgrad(t.dff16, plain(N * Q, I), 64, fq16, fqv, N * Q, I, H, G(p + "intermediate_query.dense.weight"), G(p + "intermediate_query.dense.bias"))))
       return chk(rc, "dWiq");
     // d(fq) = d_pre3 (residual) + du Wiq  -> compact dhc32 (cross layers) or the query rows of dh1
@@ -342,9 +360,9 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-t ln bwd");
       const char* dpt16 = t.dpre16 + (size_t)N * Q * H * 2;
       const float* dpt32 = t.dpre32 + (size_t)N * Q * H;
+      if ((rc = X.gemm(dpt16, plain(N * L, H), W.wotT, nullptr, dff_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_GELU_BWD, (void*)u_t))) return chk(rc, "dff-t");
+      fork();
       if ((rc = X.wgrad(dpt16, plain(N * L, H), 64, f_t, plain(N * L, I), N * L, H, I, G(p + "output.dense.weight"), G(p + "output.dense.bias")))) return chk(rc, "dWot");
-      if ((rc = X.gemm(dpt16, plain(N * L, H), W.wotT, nullptr, dff_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_OP))) return chk(rc, "dff-t");
-      if ((rc = launch_gelu(u_t, dff_t, dff_t, (long long)N * L * I, 1, op, stream))) return chk(rc, "gelu bwd t");
       if ((rc = X.wgrad(dff_t, plain(N * L, I), 64, b.h1_16 + t16, t_view, N * L, I, H, G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"))))
         return chk(rc, "dWit");
       if ((rc = X.gemm(dff_t, plain(N * L, I), W.witT, nullptr, dh1 + t32, t_view, dpt32, plain(N * L, H), N * L, H, I, EPI_RES_F32))) return chk(rc, "d_h1t");
@@ -356,8 +374,6 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       a.dx = t.dpre2_32; a.dxv = qc_rows; a.dx16 = t.dpre2_16; a.dx16v = qc_rows;
       a.dgamma = G(p + "crossattention.output.LayerNorm.weight"); a.dbeta = G(p + "crossattention.output.LayerNorm.bias");
       if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "cross ln bwd");
-      if ((rc = X.wgrad(t.dpre2_16, qc_rows, 64, b.cctx16, qc_rows, N * Q, H, H, G(p + "crossattention.output.dense.weight"), G(p + "crossattention.output.dense.bias"))))
-        return chk(rc, "dWco");
       if ((rc = X.gemm(t.dpre2_16, qc_rows, W.wcoT, nullptr, t.dcctx16, qc_rows, nullptr, qc_rows, N * Q, H, H, EPI_OP))) return chk(rc, "d_cctx");
       AttnBwdArgs g{};
       const size_t per_sel = (size_t)N * c.heads * kv * 64;
@@ -370,21 +386,24 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       g.k_ld = g.v_ld = g.dk_ld = g.dv_ld = 64;
       g.lse = b.lse_c; g.items = N; g.heads = c.heads; g.q_rows = Q; g.kv_len = kv; g.scale = 0.125f;
       if ((rc = launch_attn_bwd(g, op, stream))) return chk(rc, "cross attention bwd");
+      fork();
+      if ((rc = X.wgrad(t.dpre2_16, qc_rows, 64, b.cctx16, qc_rows, N * Q, H, H, G(p + "crossattention.output.dense.weight"), G(p + "crossattention.output.dense.bias"))))
+        return chk(rc, "dWco");
       if ((rc = X.wgrad(t.dqc16, qc_rows, 64, b.h1_16, q_view, N * Q, H, H, G(p + "crossattention.self.query.weight"), G(p + "crossattention.self.query.bias"))))
         return chk(rc, "dWcq");
       if ((rc = X.gemm(t.dqc16, qc_rows, W.wcqT, nullptr, dh1, q_view, t.dpre2_32, qc_rows, N * Q, H, H, EPI_RES_F32))) return chk(rc, "d_h1q");
     }
+    ffn_done = done();   // behind this layer's feed-forward and cross-attention weight gradients
     // ---- self-attention block: h1 = LN(pre1), pre1 = ctx Wo^T + b + hin ----
+    if (attn_done) (void)hipStreamWaitEvent(stream, attn_done, 0);   // dpre16b / dqkv16 are about to be rewritten
     {
       LnBwdArgs a{};
       a.dy = dh1; a.dyv = all_rows; a.x = b.pre1; a.xv = all_rows; a.gamma = W.ln1g; a.eps = c.ln_eps; a.rows = N * S;
-      a.dx = t.dpre32; a.dxv = all_rows; a.dx16 = t.dpre16; a.dx16v = all_rows;
+      a.dx = t.dpre32; a.dxv = all_rows; a.dx16 = t.dpre16b; a.dx16v = all_rows;
       a.dgamma = G(p + "attention.output.LayerNorm.weight"); a.dbeta = G(p + "attention.output.LayerNorm.bias");
       if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "attn ln bwd");
     }
-    if ((rc = X.wgrad(t.dpre16, all_rows, 64, b.ctx16, all_rows, N * S, H, H, G(p + "attention.output.dense.weight"), G(p + "attention.output.dense.bias"))))
-      return chk(rc, "dWo");
-    if ((rc = X.gemm(t.dpre16, all_rows, W.woT, nullptr, t.dctx16, all_rows, nullptr, all_rows, N * S, H, H, EPI_OP))) return chk(rc, "d_ctx");
+    if ((rc = X.gemm(t.dpre16b, all_rows, W.woT, nullptr, t.dctx16, all_rows, nullptr, all_rows, N * S, H, H, EPI_OP))) return chk(rc, "d_ctx");
     {
       AttnBwdArgs g{};
       g.Q = b.qkv16; g.K = b.qkv16 + (size_t)H * 2; g.V = b.qkv16 + (size_t)2 * H * 2; g.O = b.ctx16; g.dO = t.dctx16;
@@ -397,11 +416,15 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       g.items = N; g.heads = c.heads; g.q_rows = S; g.kv_len = S; g.scale = 0.125f;
       if ((rc = launch_attn_bwd(g, op, stream))) return chk(rc, "self attention bwd");
     }
+    fork();
+    if ((rc = X.wgrad(t.dpre16b, all_rows, 64, b.ctx16, all_rows, N * S, H, H, G(p + "attention.output.dense.weight"), G(p + "attention.output.dense.bias"))))
+      return chk(rc, "dWo");
     const char* names[3] = {"query", "key", "value"};
     for (int j = 0; j < 3; ++j)
       if ((rc = X.wgrad(t.dqkv16 + (size_t)j * H * 2, plain(N * S, 3 * H), 64, b.hin16, all_rows, N * S, H, H,
                         G(p + "attention.self." + names[j] + ".weight"), G(p + "attention.self." + names[j] + ".bias"))))
         return chk(rc, "dWqkv");
+    attn_done = done();
     // gradient w.r.t. the layer input: d_pre1 (residual) + dqkv Wqkv  -> becomes dh of layer i-1
     if ((rc = X.gemm(t.dqkv16, plain(N * S, 3 * H), W.wqkvT, nullptr, dh, all_rows, t.dpre32, all_rows, N * S, H, 3 * H, EPI_RES_F32))) return chk(rc, "d_hin");
   }
@@ -417,6 +440,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       return chk(rc, "embedding bwd");
   }
   // ---- cross K/V projections: dWk / dWv of every cross layer from the head-major dK / dV cache ----
+  fork();
   for (int i = 0; i < c.layers; ++i) {
     const int cl = h->layers[i].cross_index;
     if (cl < 0) continue;
@@ -430,6 +454,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
         return chk(rc, "dWkv");
     }
   }
+  (void)hipStreamWaitEvent(stream, done(), 0);   // join: what follows on `stream` sees every gradient
   return MRA_OK;
 }
 
