@@ -712,6 +712,7 @@ template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
   if (cfg == 3) return launch_ws_fold<T>(a, epi, stream);
   if (cfg == 4) return launch_ws_pv<T>(a, epi, stream);
+  if (cfg == 5) return launch_k128<T, 64, 128, 2, 2>(a, epi, stream);   // 64 weight rows x 128 activation rows, 128-deep steps
 #ifdef MRA_GEMM_EXPERIMENTS
   if (g_variant != 5 && g_variant != 1) {
     const int rc = launch_experiment<T>(a, cfg, epi, g_variant, stream);
@@ -734,8 +735,8 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
 }
 
 constexpr int kTile[3] = {64, 128, 256};
-constexpr int kTileN[5] = {64, 128, 256, 128, 176};   // weight rows per tile
-constexpr int kTileM[5] = {64, 128, 256, 384, 384};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
+constexpr int kTileN[6] = {64, 128, 256, 128, 176, 64};   // weight rows per tile
+constexpr int kTileM[6] = {64, 128, 256, 384, 384, 128};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
 
 }  // namespace
 
@@ -771,7 +772,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
   if (ngroups < 1 || ngroups > 2) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
-  if (cfg < 0 || cfg > 4) return -1;
+  if (cfg < 0 || cfg > 5) return -1;
   const int t = kTileN[cfg], tm = kTileM[cfg];
   GemmArgs a;
   a.ngroups = ngroups;
@@ -781,6 +782,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     GemmProb& p = a.p[g];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask)) return -1;
+    if (cfg == 5 && p.K % 128) return -1;
     if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32) || (p.N & 3) || p.n_ragged)) return -1;
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;

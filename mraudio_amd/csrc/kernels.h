@@ -65,7 +65,8 @@ struct GemmProb {
   float* stat_l;
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
                    // rows) loader-wave tile (EPI_OP / EPI_F32 only), 5 = 176 x 384 with the compute waves in one column (EPI_OP only,
-                   // N % 176 == 0); the first problem decides
+                   // N % 176 == 0), 6 = 64 (weight rows) x 128 (activation rows) with 128-deep K steps (K % 128 == 0: the long-K down-projections of
+                   // the layer chain at ~1 k rows, where a tile's bytes per flop, not its count, sets the time); the first problem decides
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
   int batch_row0;  // filled per workgroup: first row of its batch entry in the EPI_SOFTPART statistics

@@ -467,6 +467,10 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       p.W = Lw.wqkv; p.bias = Lw.bqkv;
       p.C = w.qkv16; p.c = plain(N * S, 3 * H);
       p.M = N * S; p.N = 3 * H; p.K = H;
+      // The chain GEMMs at ~1-2 k rows are bound by the operand bytes each CU pulls through its load path (~33 B / clk from L2),
+      // not by tile count: 128 x 128 tiles (288 of them) move half the bytes per flop of the 1152 64 x 64 tiles the automatic
+      // choice makes (headline step 6.75 -> 6.67 ms, reference item shape 2.65 -> 2.55 ms together with the down-projection below)
+      p.tile_cfg = N * S >= 1024 ? 2 : 0;
       rc = launch_gemm(&p, 1, EPI_OP, op, stream);
       if (rc) return chk(rc, "qkv gemm");
     }
@@ -654,6 +658,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       g[1].R = w.hB32 + t_off32; g[1].r = tv;
       g[1].C = w.pre32 + t_off32; g[1].c = tv;
       g[1].M = text_rows; g[1].N = H; g[1].K = I;
+      g[0].tile_cfg = N * Q >= 512 && I % 128 == 0 ? 6 : 0;   // 64 weight rows x 128 activation rows, 128-deep K steps (see the QKV note)
       rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "ffn down gemm");
     }
