@@ -277,7 +277,7 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
     from mraudio_amd.models.eva_vit import create_eva_vit_g
 
     out = {}
-    nframes, chunk = clips * frames_per_clip, 256
+    nframes, chunk = clips * frames_per_clip, clips * frames_per_clip   # the HIP encoder takes all frames of the step in one batched pass
     for backend in ("hip", "torch"):
         try:
             if backend == "hip":
