@@ -277,15 +277,14 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
     from mraudio_amd.models.eva_vit import create_eva_vit_g
 
     out = {}
-    nframes, chunk = clips * frames_per_clip, clips * frames_per_clip   # the HIP encoder takes all frames of the step in one batched pass
-    for backend in ("hip", "torch"):
+    nframes, chunk = clips * frames_per_clip, clips * frames_per_clip   # every backend takes all frames of the step in one batched pass (its fastest setting)
+    for backend in ("hip", "hip_f16_residual", "torch"):
         try:
-            if backend == "hip":
-                vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev).eval().init_seeded_(0)
+            if backend.startswith("hip"):
+                vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev, residual="op" if backend.endswith("residual") else "fp32").eval().init_seeded_(0)
             else:
                 with torch.device(dev):
                     vit = create_eva_vit_g(224, 0, False, "fp16").eval()
-                chunk = 64
             x = torch.randn(chunk, 3, 224, 224, device=dev, dtype=torch.float16)
             with torch.no_grad():
                 vit(x)
@@ -298,6 +297,7 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
             assert y.shape == (chunk, 257, 1408)
             fl = vit.flops_per_frame() * nframes
             out[backend] = {"what": ("EVA ViT-g/14 on mra_vit_forward (hand-written gfx950 kernels, f16 operands, fp32 residual)" if backend == "hip" else
+                                     "the same with the residual stream in f16 (every add rounds to 16 bits, as LAVIS' precision=\"fp16\" encoder does)" if backend == "hip_f16_residual" else
                                      "EVA ViT-g/14, stock PyTorch f16 (SDPA + hipBLASLt)") + f", random weights, {nframes} frames in chunks of {chunk}",
                             "ms": round(t * 1e3, 1), "tflops": round(fl / t / 1e12, 1), "gflop_per_frame": round(vit_gf(fl, nframes), 1),
                             "clips_per_s_encode_only": round(clips / t, 2), "clips_per_s_encode_plus_fuse_score": round(clips / (t + fuse_s), 2)}

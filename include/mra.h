@@ -227,7 +227,9 @@ typedef struct mra_vit_cfg {
   int32_t patch;     /* 14 */
   int32_t img;       /* 224 -> (224 / 14)^2 + 1 = 257 tokens */
   float ln_eps;      /* 1e-6 */
-  int32_t op_dtype;  /* MRA_F16 (the reference's precision="fp16") or MRA_BF16: MFMA operand type; residual stream fp32 */
+  int32_t op_dtype;  /* MRA_F16 (the reference's precision="fp16") or MRA_BF16: MFMA operand type */
+  int32_t residual_dtype;  /* MRA_F32 (default: fp32 residual stream, the accurate choice) or the operand dtype (the reference's own
+                            * precision="fp16" semantics: every residual add rounds to 16 bits; half the epilogue and LayerNorm bytes) */
 } mra_vit_cfg;
 void mra_vit_cfg_default(mra_vit_cfg* cfg);
 int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out);
@@ -236,9 +238,9 @@ int mra_vit_load(mra_vit* h, const char* name, const void* src, int32_t dtype, c
 /* number of parameters not loaded yet (0 = ready) */
 int mra_vit_missing(mra_vit* h);
 size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames);
-/* frames [n, 3, img, img] (MRA_F32 or MRA_F16, normalised pixels) -> out [n, tokens, dim] fp32: the last block's output,
- * no final norm (the reference's separate video_ln, mra_modality_ln, consumes it in place). */
-int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, float* out, void* workspace, size_t workspace_bytes,
+/* frames [n, 3, img, img] (MRA_F32 or MRA_F16, normalised pixels) -> out [n, tokens, dim] in cfg.residual_dtype: the last block's
+ * output, no final norm (the reference's separate video_ln, mra_modality_ln, consumes it in place). */
+int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, void* out, void* workspace, size_t workspace_bytes,
                     void* stream);
 /* algorithmic flops of one forward over `frames` frames (2 per MAC) */
 double mra_vit_flops(mra_vit* h, int32_t frames);

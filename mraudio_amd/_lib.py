@@ -30,7 +30,7 @@ class mra_cfg(C.Structure):
 
 class mra_vit_cfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32), ("depth", C.c_int32), ("patch", C.c_int32),
-                ("img", C.c_int32), ("ln_eps", C.c_float), ("op_dtype", C.c_int32)]
+                ("img", C.c_int32), ("ln_eps", C.c_float), ("op_dtype", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/mra.h declares (tests check this)

@@ -218,7 +218,7 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
   for (int i = 0; i < FN; ++i) {
     const int nl = wn0 + i * 16 + ln;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+    if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
     const int hq = nl >> 6, d = nl & 63;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -261,6 +261,7 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
 #pragma unroll
   for (int hq = 0; hq < TN / 64; ++hq) {
     const int nb = n0 + hq * 64;
+    if (nb >= P.N) continue;   // n_mask: masked tail of a ragged last column tile (N % 64 == 0)
     long long blk;
     if constexpr (EPI == EPI_KV) {
       const int hidden = P.kv_heads * 64;
@@ -273,7 +274,12 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
     for (int u = 0; u < RPB; ++u) {
       if (!live[u]) continue;
       const int q = tid + (hq * RPB + u) * NT;
-      const typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
+      typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
+      if constexpr (EPI == EPI_RES_OP) {   // + the residual in the operand dtype, whole 16-byte chunks (the reference's fp16 add)
+        const typename Vec8<T>::type r = *reinterpret_cast<const typename Vec8<T>::type*>((const T*)P.aux + blk + rowoff[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = from_f32<T>((float)val[e] + (float)r[e]);
+      }
       *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + blk + rowoff[u]) = val;
     }
   }
@@ -361,7 +367,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a[i], b[j], acc[i][j]);
     }
   }
-  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
@@ -390,7 +396,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int WGN = 8 / WGM, WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
   constexpr int BUF = (TN + TM) * ROWB;
   constexpr int NCHUNK = (TN + TM) * 8, NLD = (NCHUNK + 255) / 256;  // 16-byte chunks of a K tile (W rows, then A rows) / loader lanes
-  constexpr bool STAGED = (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) && TN % 64 == 0;   // LDS-staged 16-bit epilogue
+  constexpr bool STAGED = (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) && TN % 64 == 0;   // LDS-staged 16-bit epilogue
   static_assert(WTN % 16 == 0 && WTM % 16 == 0 && TN % 16 == 0 && NCHUNK % 64 == 0, "tile must split over the waves; whole waves per DMA piece");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -616,7 +622,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_k128_kernel(const GemmArgs
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a[i], b[j], acc[i][j]);
     }
   }
-  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV) {
+  if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
@@ -659,6 +665,7 @@ int launch_k(KFN kfn, const GemmArgs& a, int threads, size_t lds, hipStream_t st
     case EPI_KV: { constexpr int E = EPI_KV; return KERNEL_EXPR; }           \
     case EPI_GELU_BOTH: { constexpr int E = EPI_GELU_BOTH; return KERNEL_EXPR; } \
     case EPI_GELU_BWD: { constexpr int E = EPI_GELU_BWD; return KERNEL_EXPR; }   \
+    case EPI_RES_OP: { constexpr int E = EPI_RES_OP; return KERNEL_EXPR; }       \
     default: return -2;                                     \
   }
 
@@ -783,7 +790,8 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask)) return -1;
     if (cfg == 5 && p.K % 128) return -1;
-    if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32) || (p.N & 3) || p.n_ragged)) return -1;
+    if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32 && epi != EPI_RES_OP && epi != EPI_OP && epi != EPI_GELU_OP) || (p.N & 3) || p.n_ragged)) return -1;
+    if (p.n_mask && epi != EPI_RES_F32 && epi != EPI_F32 && (p.N & 63)) return -1;   // the 16-bit epilogues leave in 64-column blocks
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;
@@ -791,7 +799,8 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
-    if ((epi == EPI_OP || epi == EPI_GELU_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
+    if ((epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_RES_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
+    if (epi == EPI_RES_OP && (!p.aux || p.n_ragged)) return -1;
     if ((epi == EPI_GELU_BOTH || epi == EPI_GELU_BWD) && (!p.aux || (p.c.ld & 3) || (p.c.item_stride & 3) || p.n_ragged)) return -1;
     p.mtiles = (p.M + tm - 1) / tm;
     p.ntiles = (p.N + t - 1) / t;

@@ -17,6 +17,8 @@ enum GemmEpi {
   EPI_KV = 4,       // C(op dtype) head-major K/V cache, see GemmProb::kv_*
   EPI_GELU_BOTH = 6, // training forward: aux(op dtype) = acc + bias (the pre-activation the backward needs), C(op dtype) = gelu_erf of it
   EPI_GELU_BWD = 7,  // training backward: C(op dtype) = acc * gelu'(aux): the GELU gradient inside the data-gradient GEMM
+  EPI_RES_OP = 8,   // C(op dtype) = op(acc + bias) + Rop: residual stream kept in the operand dtype (the ViT under precision="fp16");
+                    // Rop is GemmProb::aux (op dtype, addressed like C; may alias C: updated in place)
   EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile
                     // sum go to stat_m / stat_l [row][ntiles] (176 x 384 loader-wave tile only: a wave holds whole tile rows)
 };

@@ -271,7 +271,7 @@ int copy_f32(const void* src, int dtype, float* dst, long long n, hipStream_t st
 extern "C" {
 
 void mra_vit_cfg_default(mra_vit_cfg* c) {
-  c->dim = 1408; c->heads = 16; c->mlp = 6144; c->depth = 39; c->patch = 14; c->img = 224; c->ln_eps = 1e-6f; c->op_dtype = MRA_F16;
+  c->dim = 1408; c->heads = 16; c->mlp = 6144; c->depth = 39; c->patch = 14; c->img = 224; c->ln_eps = 1e-6f; c->op_dtype = MRA_F16; c->residual_dtype = MRA_F32;
 }
 
 int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
@@ -282,6 +282,7 @@ int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
   if ((3 * c.heads * HD_PAD) % 256 || c.mlp <= 0 || c.mlp % 256) return fail(MRA_EINVAL, "3 * heads * 96 and mlp must be multiples of 256");
   if (c.patch <= 0 || c.img <= 0 || c.img % c.patch || c.depth <= 0) return fail(MRA_EINVAL, "bad patch / image size / depth");
   if (c.op_dtype != MRA_F16 && c.op_dtype != MRA_BF16) return fail(MRA_EINVAL, "op_dtype must be MRA_F16 or MRA_BF16");
+  if (c.residual_dtype != MRA_F32 && c.residual_dtype != c.op_dtype) return fail(MRA_EINVAL, "residual_dtype must be MRA_F32 or the operand dtype");
   mra_vit* h = new mra_vit();
   h->cfg = c;
   h->np = c.img / c.patch;
@@ -368,14 +369,15 @@ size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames) {
   if (!h || frames <= 0) return 0;
   const size_t M = (size_t)frames * h->S;
   const size_t wide = std::max<size_t>(std::max<size_t>(h->nqkv, h->cfg.mlp), h->kpad);
-  return align_up(M * h->cfg.dim * 2) + align_up(M * wide * 2);
+  // r16: the fp32 embeddings are staged behind the patches inside the wide buffer (patches M x kpad x 2 + M x dim x 4 <= M x wide x 2)
+  return align_up(M * h->cfg.dim * 2) + align_up(M * wide * 2) + 4096;
 }
 
-int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, void* out_, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!h) return fail(MRA_EINVAL, "null handle");
   if (n < 0) return fail(MRA_EINVAL, "negative frame count");
   if (n == 0) return MRA_OK;
-  if (!frames || !out || !workspace) return fail(MRA_EINVAL, "null argument");
+  if (!frames || !out_ || !workspace) return fail(MRA_EINVAL, "null argument");
   if (dtype != MRA_F32 && dtype != MRA_F16) return fail(MRA_EINVAL, "frames must be f32 or f16");
   if (mra_vit_missing(h) > 0) return fail(MRA_ESTATE, std::to_string(mra_vit_missing(h)) + " ViT parameters not loaded");
   if (workspace_bytes < mra_vit_workspace_bytes(h, n)) return fail(MRA_ENOMEM, "workspace too small: need " + std::to_string(mra_vit_workspace_bytes(h, n)));
@@ -387,6 +389,8 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
   hipStream_t st = as_stream(stream_);
   char* a16 = (char*)workspace;
   char* big = a16 + align_up((size_t)M * D * 2);
+  const bool r16 = c.residual_dtype != MRA_F32;      // residual stream in the operand dtype (the reference's precision="fp16")
+  float* out = r16 ? reinterpret_cast<float*>(big + align_up((size_t)n * h->np * h->np * h->kpad * 2)) : (float*)out_;   // r16: fp32 embeddings are staged, then converted
   int rc;
   {   // patches -> x[:, 1:, :] = patch GEMM + bias + pos[1:]; x[:, 0, :] = cls + pos[0]
     const long long total = (long long)n * h->np * h->np * h->kpad;
@@ -408,7 +412,10 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
     rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
     if (rc) return chk(rc, "patch embedding gemm");
     hipLaunchKernelGGL(vit_cls_kernel, dim3((unsigned)(((long long)n * D + 255) / 256)), dim3(256), 0, st, out, h->cls, h->pos, n, S, D);
+    if (r16 && (rc = launch_convert(out, MRA_F32, out_, c.op_dtype, M * D, st))) return chk(rc, "embedding convert");
   }
+  const int xdt = r16 ? c.op_dtype : MRA_F32;       // dtype code of the residual stream for the LayerNorm kernel
+  void* x = r16 ? out_ : (void*)out;
   const size_t attn_lds = 2 * KS_PAD * KV_PITCH;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> (h->device & 63) & 1)) {
@@ -420,7 +427,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
   const float sl2 = LOG2E / sqrtf((float)hd);
   for (int li = 0; li < c.depth; ++li) {
     const VitLayer& L = h->layers[li];
-    rc = launch_modality_ln(out, 0, nullptr, n, S, D, L.n1g, L.n1b, c.ln_eps, a16, op, st);
+    rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n1g, L.n1b, c.ln_eps, a16, op, st);
     if (rc) return chk(rc, "vit ln1");
     {
       GemmProb p{};
@@ -434,12 +441,12 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
     {
       GemmProb p{};
       p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;
-      p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
+      p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
       p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
-      rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
+      rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit projection gemm");
     }
-    rc = launch_modality_ln(out, 0, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
+    rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
     if (rc) return chk(rc, "vit ln2");
     {
       GemmProb p{};
@@ -451,9 +458,9 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, fl
     {
       GemmProb p{};
       p.A = big; p.a = plain((int)M, I); p.W = L.wfc2; p.bias = L.bfc2;
-      p.R = out; p.r = plain((int)M, D); p.C = out; p.c = plain((int)M, D);
+      p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
       p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
-      rc = launch_gemm(&p, 1, EPI_RES_F32, op, st);
+      rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit fc2 gemm");
     }
   }

@@ -136,9 +136,10 @@ class HipEvaViTg(EvaViTg):
     """The same encoder on the HIP extension (``mra_vit_*``, ``mraudio_amd/csrc/vit.hip``): this module is the parameter
     container (state_dict keys unchanged); ``forward`` runs ALL given frames as one batched pass of hand-written gfx950
     kernels -- the four GEMMs per block on the loader-wave MFMA kernels with bias / GELU / residual fused, a 96-padded
-    attention core, fp32 residual stream -- and returns ``[n, 257, 1408]`` fp32.  No CPU path."""
+    attention core -- and returns ``[n, 257, 1408]``: fp32 with the default fp32 residual stream, the operand dtype with
+    ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  No CPU path."""
 
-    def __init__(self, *args, op_dtype: torch.dtype = torch.float16, device=None, **kw):
+    def __init__(self, *args, op_dtype: torch.dtype = torch.float16, residual: str = "fp32", device=None, **kw):
         super().__init__(*args, **kw)
         import ctypes as C
 
@@ -149,7 +150,11 @@ class HipEvaViTg(EvaViTg):
         blk = self.blocks[0]
         cfg = _lib.mra_vit_cfg(self.num_features, blk.attn.heads, blk.fc1.out_features, len(self.blocks), self.patch_embed.kernel_size[0],
                                self.patch_embed.kernel_size[0] * int(round((self.pos_embed.shape[1] - 1) ** 0.5)), 1e-6,
-                               _lib.MRA_BF16 if op_dtype == torch.bfloat16 else _lib.MRA_F16)
+                               _lib.MRA_BF16 if op_dtype == torch.bfloat16 else _lib.MRA_F16,
+                               _lib.MRA_F32 if residual == "fp32" else (_lib.MRA_BF16 if op_dtype == torch.bfloat16 else _lib.MRA_F16))
+        if residual not in ("fp32", "op"):
+            raise ValueError("residual must be 'fp32' (default) or 'op' (the operand dtype: the reference's precision='fp16' semantics)")
+        self._out_dtype = torch.float32 if residual == "fp32" else op_dtype
         with torch.cuda.device(self._device):
             _lib.check(_lib.lib().mra_vit_create(C.byref(cfg), C.byref(self._handle)), "mra_vit_create")
         self._dirty, self._ws = True, None
@@ -198,7 +203,7 @@ class HipEvaViTg(EvaViTg):
             x = x.float()
         x = x.contiguous()
         n = int(x.shape[0])
-        out = torch.empty(n, self.pos_embed.shape[1], self.num_features, dtype=torch.float32, device=self._device)
+        out = torch.empty(n, self.pos_embed.shape[1], self.num_features, dtype=self._out_dtype, device=self._device)
         if n == 0:
             return out
         with torch.cuda.device(self._device):

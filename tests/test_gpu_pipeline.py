@@ -96,3 +96,28 @@ def test_llm_decode_path_with_a_stock_llama():
     loss = model.forward_llm(batch)["loss"]
     assert torch.isfinite(loss)
     assert "llm_model.lm_head.weight" not in model.state_dict()     # the LLM is not part of this model's checkpoint
+
+
+def test_checkpoint_argument_loads_the_reference_key_names(tmp_path):
+    """``XInstructBLIP(model_path, audio_path)`` used to ignore both arguments and always run on the synthetic init.
+    ``checkpoint=`` (CLI ``--checkpoint``) loads a weights-only ``.pth`` with the reference's key names (models/xinstructblip.py:
+    759-816 routing); a file with none of the model's keys is an error, not a silent no-op."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    dev = torch.device("cuda:0")
+    src = XInstructBLIP(seed=7, perturb=True, device=dev)
+    g = torch.Generator().manual_seed(2)
+    samples = {"video_embeds": torch.randn(1, 4, 40, 1408, generator=g), "audio_embeds": torch.randn(1, 4, 24, 768, generator=g),
+               "text_input": ["Query: a cat jumps.\nRelevant windows: "], "timestamps": [[0, 2, 4, 6]], "duration": [8]}
+    want = src.encode_fuse(samples)["fused"].clone()
+    path = tmp_path / "weights.pth"
+    torch.save({"model": {k: v.cpu() for k, v in src.state_dict().items()}}, path)
+    other = XInstructBLIP("/path/to/vicuna", "/path/to/beats.pt", seed=0, device=dev, checkpoint=str(path))
+    assert "checkpoint" in other.weights_source
+    assert torch.equal(other.encode_fuse(samples)["fused"], want)
+    fresh = XInstructBLIP(seed=0, device=dev)
+    assert fresh.weights_source.startswith("synthetic") and not torch.equal(fresh.encode_fuse(samples)["fused"], want)
+    bogus = tmp_path / "bogus.pth"
+    torch.save({"llm_model.weight": torch.zeros(2)}, bogus)
+    with pytest.raises(RuntimeError):
+        XInstructBLIP(seed=0, device=dev, checkpoint=str(bogus))

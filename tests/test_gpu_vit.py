@@ -54,6 +54,22 @@ def test_hip_vit_matches_the_hf_vectors_and_the_fp32_restatement(pair, golden_di
     assert (ym[3:] - y).abs().max().item() < 1e-4
 
 
+def test_hip_vit_with_the_reference_precision_residual(pair, dev):
+    """``residual="op"``: the residual stream in f16, every add rounding to 11 bits -- what LAVIS' ``precision="fp16"`` encoder does.
+    Against the fp32 restatement the bar is the f16 resolution of values up to ~7 accumulated over 2 x DEPTH adds."""
+    ref, _ = pair
+    hip16 = HipEvaViTg(depth=DEPTH, device=dev, residual="op").eval()
+    hip16.load_state_dict(ref.state_dict())
+    frames = make_frames()
+    y = hip16(frames.to(dev))
+    assert y.dtype == torch.float16 and y.shape == (2, 257, 1408)
+    with torch.no_grad():
+        want = ref(frames)
+    y = y.float().cpu()
+    assert torch.isfinite(y).all() and (y - want).abs().max().item() < 4e-2
+    assert ((y - want).norm() / want.norm()).item() < 4e-3
+
+
 def test_hip_vit_ragged_batches_and_errors(pair, dev):
     from mraudio_amd import MraError
 
