@@ -39,6 +39,9 @@ __device__ __forceinline__ long long view_off(const RowView& v, int m) {
 
 // XCD-contiguous remap (bijective for any grid size), group lookup, 8-row-tile panels
 template <int TN, int TM>
+__device__ __forceinline__ GemmProb tile_of(const GemmArgs& args, int id, int& n0, int& m0);
+
+template <int TN, int TM>
 __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int& m0) {
   int id = blockIdx.x;
   {
@@ -46,6 +49,12 @@ __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
+  return tile_of<TN, TM>(args, id, n0, m0);
+}
+
+// tile `id` of the launch (after the XCD remap): its problem (batch entry applied) and origin
+template <int TN, int TM>
+__device__ __forceinline__ GemmProb tile_of(const GemmArgs& args, int id, int& n0, int& m0) {
   const int g = (args.ngroups > 1 && id >= args.p[1].tile_begin) ? 1 : 0;
   GemmProb P = args.p[g];
   int pid = id - P.tile_begin;
@@ -58,6 +67,18 @@ __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int
     P.C = (char*)P.C + b * P.c_bs_bytes;
     if (P.bias) P.bias += (long long)b * P.bias_bs;
     P.batch_row0 = b * P.M;
+  }
+  if (const int gn = args.order & 0xff) {
+    // weight-resident order: panels of gn column tiles, walked down the rows with the columns fastest -- an XCD's 32 concurrent
+    // workgroups cover (32 / gn) row tiles x gn column tiles, the gn weight tiles stay in its L2 while the activation rows stream
+    const int per_panel = gn * P.mtiles;
+    const int panel = pid / per_panel;
+    const int first_n = panel * gn;
+    const int gsz = min(gn, P.ntiles - first_n);
+    const int in_panel = pid - panel * per_panel;
+    n0 = (first_n + in_panel % gsz) * TN;
+    m0 = (in_panel / gsz) * TM;
+    return P;
   }
   constexpr int GM = 8;
   const int per_panel = GM * P.ntiles;
@@ -750,6 +771,8 @@ constexpr int kTileM[6] = {64, 128, 256, 384, 384, 128};   // activation rows pe
 
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 void gemm_force_variant(int v) { g_variant = v; }
+static int g_order = 0;
+void gemm_set_tile_order(int order) { g_order = order; }
 void gemm_set_debug_buffer(unsigned long long* p) { g_dbg = p; }
 
 int gemm_pick_config(const GemmProb* probs, int ngroups) {
@@ -810,6 +833,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
   if (ngroups == 1) a.p[1] = a.p[0];
   a.total_tiles = tiles;
   a.dbg = g_dbg;
+  a.order = g_order ? g_order : probs[0].order;
   return op_dtype == OP_F16 ? launch_t<f16>(a, cfg, epi, stream) : launch_t<bf16>(a, cfg, epi, stream);
 }
 

@@ -69,6 +69,8 @@ struct GemmProb {
                    // rows) loader-wave tile (EPI_OP / EPI_F32 only), 5 = 176 x 384 with the compute waves in one column (EPI_OP only,
                    // N % 176 == 0), 6 = 64 (weight rows) x 128 (activation rows) with 128-deep K steps (K % 128 == 0: the long-K down-projections of
                    // the layer chain at ~1 k rows, where a tile's bytes per flop, not its count, sets the time); the first problem decides
+  int order;       // tile walk: 0 = panels of 8 row tiles, rows fastest; gn > 0 = panels of gn column tiles walked down the rows, columns
+                   // fastest (measured better for the ViT's N = 1408 GEMMs: all 6 column tiles of a row tile run together)
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
   int batch_row0;  // filled per workgroup: first row of its batch entry in the EPI_SOFTPART statistics
@@ -79,6 +81,7 @@ struct GemmArgs {
   int ngroups;
   int total_tiles;
   unsigned long long* dbg;  // diagnostic builds only (gemm_set_debug_buffer): per-wave cycle sums
+  int order;                // 0: 8-row-tile panels, rows fastest; gn > 0: panels of gn column tiles, columns fastest (GemmProb::order of the first problem)
 };
 
 // Returns 0 on success, <0 on bad shapes.  All problems of one launch share dtype / epilogue.
@@ -87,6 +90,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
 int gemm_pick_config(const GemmProb* probs, int ngroups);
 void gemm_force_config(int cfg);  // -1 = automatic (default)
 void gemm_set_debug_buffer(unsigned long long* dev_buf);  // variant 4 (stamped v1) writes 4 u64 per wave
+void gemm_set_tile_order(int order);      // overrides GemmProb::order for every later launch when != 0 (A/B runs)
 void gemm_force_variant(int v);   // 5 = default (warp-specialised 256x256, two-buffer small tiles); 0 ring, 1 two-buffer,
                                   // 2 +L2 prefetch, 3 +spread DMA issue, 4 stamped diagnostic -- kept for A/B runs
 

@@ -442,7 +442,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       GemmProb p{};
       p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;
       p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
-      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
+      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
       rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit projection gemm");
     }
@@ -459,7 +459,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       GemmProb p{};
       p.A = big; p.a = plain((int)M, I); p.W = L.wfc2; p.bias = L.bfc2;
       p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
-      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3;
+      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
       rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
       if (rc) return chk(rc, "vit fc2 gemm");
     }

@@ -90,9 +90,60 @@ static void fold_ab(int rounds) {
          t_s, fl / t_s / 1e9, t_p, fl / t_p / 1e9, t_b, o_s, fl / o_s / 1e9, o_r, o_p, fl / o_p / 1e9, o_s + o_r + o_p);
 }
 
+// tile orders of the 256 x 256 loader-wave kernel on the big shapes (K/V projection, the ViT's four GEMMs over 1024 frames)
+static void order_ab(int rounds) {
+  const Shape shapes[] = {
+      {"kvproj video 32x8224", 32 * 8224, 9216, 1408, EPI_KV, -1},
+      {"vit qkv 263168x1408->4608", 1024 * 257, 4608, 1408, EPI_OP, -1},
+      {"vit fc1 263168x1408->6144", 1024 * 257, 6144, 1408, EPI_GELU_OP, -1},
+      {"vit fc2 263168x6144->1408", 1024 * 257, 1408, 6144, EPI_F32, 3},
+      {"vit proj 263168x1408->1408", 1024 * 257, 1408, 1408, EPI_F32, 3},
+  };
+  const size_t nA = (size_t)1024 * 257 * 6144, nW = (size_t)9216 * 1408, nC = (size_t)1024 * 257 * 9216;
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)1 << 24);
+  for (auto& v : h) v = (_Float16)d(rng);
+  _Float16 *A, *W, *C;
+  float* bias;
+  CK(hipMalloc((void**)&A, nA * 2)); CK(hipMalloc((void**)&W, nW * 2)); CK(hipMalloc((void**)&C, nC * 2));
+  for (size_t off = 0; off < nA; off += h.size()) CK(hipMemcpy(A + off, h.data(), std::min(h.size(), nA - off) * 2, hipMemcpyHostToDevice));
+  for (size_t off = 0; off < nW; off += h.size()) CK(hipMemcpy(W + off, h.data(), std::min(h.size(), nW - off) * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&bias, 16384 * 4)); CK(hipMemset(bias, 0, 16384 * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int orders[] = {0x10000, 2, 4, 8, 16};   // 0x10000: the default walk (rows fastest in panels of 8 row tiles)
+  for (auto& s : shapes) {
+    GemmProb p{};
+    p.A = A; p.a = RowView{0, s.M, s.K}; p.W = W; p.bias = bias; p.C = C; p.c = RowView{0, s.M, s.N};
+    p.M = s.M; p.N = s.N; p.K = s.K; p.tile_cfg = s.cfg > 0 ? s.cfg : 0; p.n_mask = s.N % 256 != 0;
+    if (s.epi == EPI_KV) { p.kv_tokens = s.M / 32; p.kv_items = 32; p.kv_heads = 12; }
+    printf("%-30s", s.name);
+    for (int o : orders) {
+      gemm_set_tile_order(o);
+      double best = 1e30;
+      for (int r = 0; r < rounds; ++r) {
+        if (launch_gemm(&p, 1, s.epi, OP_F16, 0)) { printf("launch failed\n"); return; }
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 3; ++i) launch_gemm(&p, 1, s.epi, OP_F16, 0);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, (double)ms / 3);
+      }
+      printf("  gn%-2d %5.0f", o & 0xff, 2.0 * s.M * s.N * s.K / best / 1e9);
+    }
+    printf("  TF/s\n");
+    fflush(stdout);
+  }
+  gemm_set_tile_order(0);
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
+  if (argc > 2 && !strcmp(argv[2], "order")) { order_ab(rounds); return 0; }
   const int only = argc > 2 ? atoi(argv[2]) : -1;      // run a single shape (profiling)
   const int only_variant = argc > 3 ? atoi(argv[3]) : -1;
   const Shape shapes[] = {

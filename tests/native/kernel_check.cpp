@@ -93,7 +93,7 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
   const int S = views ? 9 : rpi, off = views ? 3 : 0;
   const int items = (M + rpi - 1) / rpi;
   struct G {
-    std::vector<uint16_t> A, W;
+    std::vector<uint16_t> A, W, R16;
     std::vector<float> bias, R;
     RowView av, cv, rv;
     size_t csz;
@@ -127,6 +127,12 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
     dC32.push_back(new Dev<float>(x.csz));
     dC16.back()->fill(0xFF);
     dC32.back()->fill(0xFF);
+    if (epi == EPI_RES_OP) {   // in place: C holds the residual in the operand dtype
+      x.R16.resize(x.csz);
+      for (auto& v : x.R16) v = to_op(frand(), op);
+      delete dC16.back();
+      dC16.back() = new Dev<uint16_t>(x.R16);
+    }
     GemmProb& p = probs[q];
     memset(&p, 0, sizeof(p));
     p.A = dA[q]->p + (size_t)off * K;
@@ -150,6 +156,7 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
     } else {
       p.C = dC16[q]->p + (size_t)off * ldc;
       p.c = x.cv;
+      if (epi == EPI_RES_OP) p.aux = p.C;
     }
   }
   const int rc = launch_gemm(probs.data(), groups, epi, op, 0);
@@ -171,6 +178,7 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
         double got;
         if (epi == EPI_GELU_OP) acc = 0.5 * acc * (1.0 + erf(acc / sqrt(2.0)));
         if (epi == EPI_RES_F32) acc += x.R[(size_t)off * N + voff(x.rv, m) + n];
+        if (epi == EPI_RES_OP) acc = from_op(to_op((float)acc, op), op) + from_op(x.R16[(size_t)off * ldc + voff(x.cv, m) + n], op);
         if (epi == EPI_RES_F32 || epi == EPI_F32) {
           got = c32[(size_t)off * ldc + voff(x.cv, m) + n];
         } else if (epi == EPI_KV) {
@@ -189,7 +197,7 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
   char name[160];
   snprintf(name, sizeof(name), "gemm cfg%d epi%d %s M%d N%d K%d views%d groups%d", cfg, epi, op == OP_F16 ? "f16" : "bf16", M, N, K,
            (int)views, groups);
-  const bool lowp_out = epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_KV;
+  const bool lowp_out = epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_KV || epi == EPI_RES_OP;
   report(name, worst, op == OP_F16 ? (lowp_out ? 2e-3 : 5e-4) : (lowp_out ? 1.2e-2 : 4e-3));
   for (auto p : dA) delete p;
   for (auto p : dW) delete p;
@@ -936,6 +944,12 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
+  gemm_set_tile_order(8);   // column-fastest panels (the ViT's N = 1408 GEMMs)
+  test_gemm(2, EPI_RES_F32, OP_F16, 1300, 512, 320, true, 2);
+  test_gemm_masked(2, EPI_RES_F32, OP_F16, 1500, 1408, 192);
+  test_gemm(1, EPI_OP, OP_F16, 700, 640, 128, true);
+  gemm_set_tile_order(0);
   test_gemm_masked(2, EPI_RES_F32, OP_F16, 700, 352, 128);   // N = 1.4 column tiles of 256, the tail is neither read nor stored
   test_gemm_masked(2, EPI_F32, OP_F16, 300, 1408, 192);
   test_gemm_masked(1, EPI_RES_F32, OP_BF16, 200, 200, 64);
