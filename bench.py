@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold_stream", "fold384"],
+    ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold_stream", "fold384", "fold_rescale_pass"],
                     help="cross-attention formulation (auto = folded from Kv >= 2048; fold_stream / fold384: A/B variants)")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
@@ -175,7 +175,7 @@ def main():
     ncross, H, E = 6, 768, ENC_WIDTH["video"]
     kv_flops = 2.0 * n_local * kv["video"] * E * (ncross * 2 * H)
     Q, R = 32, 12 * 32
-    folded = args.cross_mode in ("fold", "fold_stream", "fold384") or (args.cross_mode == "auto" and kv["video"] >= 2048)
+    folded = args.cross_mode in ("fold", "fold_stream", "fold384", "fold_rescale_pass") or (args.cross_mode == "auto" and kv["video"] >= 2048)
     if folded:
         # folded cross-attention: the library's event pair brackets the launches of cross layer 0.  Executed work = the
         # re-associated products actually run (that is what `frac` prices); algorithmic work = what the reference
@@ -240,8 +240,11 @@ def main():
                                      + ("per-head Q' GEMM (gemm_kernel<64,64>) + Q' re-pack + fold_stream_kernel<scores> + row statistics + fold_stream_kernel<pv> "
                                         "+ per-head context GEMM" if args.cross_mode == "fold_stream" else
                                         "per-head Q' GEMM (gemm_kernel<64,64>) + batched scores GEMM (gemm_ws_kernel<176x384, EPI_SOFTPART>: exp2(s - tile max) in f16 "
-                                        "+ tile statistics) + softmax_rescale_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384>, encoder tokens as the K-major "
-                                        "operand) + per-head context GEMM")),
+                                        "+ tile statistics) + " + ("softmax_rescale_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384>, encoder tokens as the K-major operand)"
+                                                                    if args.cross_mode == "fold_rescale_pass" else
+                                                                    "fold_rowfactor_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384, PSC>: encoder tokens as the K-major "
+                                                                    "operand, row factors applied to the P~ fragments in registers)")
+                                        + " + per-head context GEMM")),
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                           "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_exec,

@@ -135,13 +135,16 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
  *   2  folded:    per layer S = (Q W_k) enc^T, P = softmax(S / 8), context = (P enc) W_v^T + b_v -- half the flops
  *                 at any Kv (the 32 queries are fewer than the 64 head dimensions).  With 12 heads and enc_width % 176 == 0
  *                 the two big products run on the 176 x 384 loader-wave GEMM tile with the softmax split over the
- *                 176-column tiles (tile statistics in the scores epilogue, one rescale pass over P); otherwise on
- *                 128 x 128 tiles with fp32 score rows;
+ *                 176-column tiles: tile statistics in the scores epilogue, row factors exp2(m_tile - m_row) / L from a
+ *                 small kernel, applied by the P . enc GEMM to its P~ fragments on their way into the MFMA (P is written
+ *                 once and read once); otherwise on 128 x 128 tiles with fp32 score rows;
  *   0  automatic (default): folded from Kv >= 2048;
  *   3  as 2 on the 128 x 384 loader-wave tile (A/B runs: no faster);
  *   4  as 2 on the streaming kernels of fold_stream.hip (f16 only: row operands straight to registers two K steps
  *      ahead, slab ring of four LDS slots, power-of-two tile factors applied in registers, no rescale pass).  Measured
  *      13 % SLOWER than mode 2 -- both forms sit on the per-CU load path, DESIGN.md section 8 -- kept, tested, opt-in.
+ *   5  as 2 with the row factors applied by a separate rescale pass over P (the round-1 form; same results bit for bit, one more
+ *      read and write of P per layer: kept as the measured alternative).
  * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on

@@ -121,6 +121,24 @@ __global__ void __launch_bounds__(256) softmax_rescale_kernel(T* P, long long ld
   }
 }
 
+// The same row statistics as softmax_rescale_kernel, but only the factors leave: one wave per row, factors in the [item][tile][512] layout
+// the P . enc GEMM's loader waves copy into LDS one tile slice (2 KB) at a time.
+__global__ void __launch_bounds__(256) fold_rowfactor_kernel(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sm = stat_m + (long long)row * ntiles;
+  const float* sl = stat_l + (long long)row * ntiles;
+  float m = -3.0e38f;
+  for (int t = lane; t < ntiles; t += 64) m = fmaxf(m, sm[t]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int t = lane; t < ntiles; t += 64) l += __builtin_amdgcn_exp2f(sm[t] - m) * sl[t];
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+  const int item = row / R, r = row - item * R;
+  for (int t = lane; t < ntiles; t += 64) factors[((long long)item * ntiles + t) * 512 + r] = __builtin_amdgcn_exp2f(sm[t] - m) * inv;
+}
+
 // dst[b][c][r] = src[b][r][c] for r < R, 0 for R <= r < ld_d; 32 x 32 tiles, grid (ceil(C/32), ceil(ld_d/32), batch)
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_pad_kernel(const T* src, T* dst, int R, int C, int ld_d, long long src_bs,
@@ -187,6 +205,13 @@ int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p,
   if (op_dtype == OP_F16) MRA_SM_T(f16); else MRA_SM_T(bf16);
 #undef MRA_SM_T
 #undef MRA_SM
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_fold_rowfactor(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (ntiles <= 0 || R <= 0 || R > 512 || rows % R) return -1;
+  hipLaunchKernelGGL(fold_rowfactor_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, stat_m, stat_l, factors, rows, R, ntiles);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

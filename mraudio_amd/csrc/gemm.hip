@@ -66,6 +66,7 @@ __device__ __forceinline__ GemmProb tile_of(const GemmArgs& args, int id, int& n
     P.W = (const char*)P.W + b * P.w_bs * 2;
     P.C = (char*)P.C + b * P.c_bs_bytes;
     if (P.bias) P.bias += (long long)b * P.bias_bs;
+    if (P.pscale) P.pscale += (long long)b * P.ps_ntiles * 512;
     P.batch_row0 = b * P.M;
   }
   if (const int gn = args.order & 0xff) {
@@ -411,11 +412,13 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
 // (head, query) rows of an item against a 128-row slab of the other operand, so that operand streams once).
 // 176 x 384 with the 8 compute waves in one column (WGM = 8): P . enc of the folded path -- N = 1408 = 8 x 176, so
 // 32 items give exactly 256 workgroups, one per CU, and each streams its 176-row slab of enc^T exactly once.
-template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4, bool NTW = false, bool WKM = false>  // NODMA: diagnostic only (wrong results); NTW: non-temporal loads of the weight-side slab; WKM: K-major W (GemmProb::w_ld)
+template <typename T, int EPI, bool NODMA = false, int TN = 256, int TM = 256, int WGM = 4, bool NTW = false, bool WKM = false, bool PSC = false>  // NODMA: diagnostic only (wrong results); NTW: non-temporal loads of the weight-side slab; WKM: K-major W (GemmProb::w_ld); PSC: GemmProb::pscale
 __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
   constexpr int BK = 64, ROWB = BK * 2;
   constexpr int WGN = 8 / WGM, WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
   constexpr int BUF = (TN + TM) * ROWB;
+  constexpr int PS_TILE = 176, GT_OFF = 2 * BUF, GT_SLICE = 2048;   // PSC: ring of four factor slices (one per 176-column tile of P~) behind the K buffers
+  static_assert(!PSC || (TM <= 512 && PS_TILE % 8 == 0), "factor slices hold 512 rows; an 8-k fragment piece never straddles a tile");
   constexpr int NCHUNK = (TN + TM) * 8, NLD = (NCHUNK + 255) / 256;  // 16-byte chunks of a K tile (W rows, then A rows) / loader lanes
   constexpr bool STAGED = (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) && TN % 64 == 0;   // LDS-staged 16-bit epilogue
   static_assert(WTN % 16 == 0 && WTM % 16 == 0 && TN % 16 == 0 && NCHUNK % 64 == 0, "tile must split over the waves; whole waves per DMA piece");
@@ -466,12 +469,28 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
           }
         }
     };
+    // PSC: loader wave 8 also keeps the factor slices of the P~ tiles that K step kt + 1 touches in LDS (slot t & 3; a slot's previous
+    // tenant, tile t - 4, was last read 8 K steps ago)
+    int gt_next = 0;
+    auto stage_factors = [&](int kt) {
+      if constexpr (PSC) {
+        if (wave != 8) return;
+        const int t_hi = (kt * BK + BK - 1) / PS_TILE;
+        for (; gt_next <= t_hi && gt_next < P.ps_ntiles; ++gt_next) {
+          const char* sg = (const char*)(P.pscale + (long long)gt_next * 512) + lane * 16;
+          char* dg = smem + GT_OFF + (gt_next & 3) * GT_SLICE;
+          glds16(sg, dg);
+          glds16(sg + 1024, dg + 1024);
+        }
+      }
+    };
     stage(0, 0);
+    stage_factors(0);
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + 1 < nk && !(NODMA && kt >= 1)) stage((kt + 1) & 1, kt + 1);
+      if (kt + 1 < nk && !(NODMA && kt >= 1)) { stage((kt + 1) & 1, kt + 1); stage_factors(kt + 1); }
     }
     if constexpr (STAGED) {
       __syncthreads();  // K loop reads over
@@ -514,6 +533,27 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       typename Vec8<T>::type b[FM];
 #pragma unroll
       for (int j = 0; j < FM; ++j) b[j] = lds_read8<T>(xb + j * 16 * ROWB + foff[ks]);
+      if constexpr (PSC) {
+        // this lane's 8 k of the fragment lie inside one 176-column tile of P~: one factor per (row, tile), the rescale pass's arithmetic
+        const int t = (kt * BK + ks * 32 + 8 * (lane >> 4)) / PS_TILE;
+        const float* gt = reinterpret_cast<const float*>(smem + GT_OFF + (t & 3) * GT_SLICE) + wm0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const float gf = gt[j * 16];
+          if constexpr (sizeof(T) == 2 && __is_same(T, f16)) {
+            // packed f16 multiplies (4 per fragment) with the factor rounded to f16: the fp32 form of the rescale pass costs 28 VALU
+            // instructions per fragment and made this load-bound kernel compute-bound (0.236 -> 0.288 ms)
+            const typename Vec8<T>::type prod = b[j] * (f16)gf;
+            typename Vec8<T>::type zero;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zero[e] = (f16)0.f;
+            b[j] = t < P.ps_ntiles ? prod : zero;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[j][e] = t < P.ps_ntiles ? from_f32<T>((float)b[j][e] * gf) : from_f32<T>(0.f);
+          }
+        }
+      }
       if constexpr (WKM) {
         // fragment of weight tile i: lane (column n = 16 i + (lane & 15)) needs k = 32 ks + 8 (lane >> 4) .. + 7 = two
         // transposed 4 x 16 blocks of the [k][n] tile; the next fragment's reads fly while this one's MFMAs issue
@@ -717,6 +757,10 @@ int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (wei
   constexpr size_t lds = 2 * (176 + 384) * 128;
   if (a.p[0].w_ld > 0) {   // K-major weights (P . enc straight from the encoder tokens)
     if (epi != EPI_OP) return -2;
+    if (a.p[0].pscale) {
+      if (a.p[0].M > 512 || a.p[0].ps_ntiles <= 0) return -1;
+      return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true, true>, a, 768, lds + 4 * 2048, stream);
+    }
     return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true>, a, 768, lds, stream);
   }
   // the slab (weight-side rows) is read by this workgroup only: non-temporal loads (7.40 -> 7.17 ms / step)
@@ -818,6 +862,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;
+    if (p.pscale && (!p.w_ld || cfg != 4 || p.M > 512 || p.ps_ntiles <= 0 || p.K > p.ps_ntiles * 176 + 4 * 176)) return -1;
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;

@@ -146,6 +146,7 @@ struct Work {
   char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
   float* s32;                      // scores [N][R][kvp]
   float* stat;                     // split softmax: tile maxima [N][R][ntiles], then tile sums
+  float* gfac;                     // split softmax: row factors exp2(m_tile - m_row) / L as [N][ntiles][512] for the P . enc GEMM
   float *st_m, *st_l, *ginv;       // streaming kernels: statistics [N * R][stat_ld], 1 / L [N * R]
   char* gexp;                      // tile factors f16 [N * R][stat_ld]
   int nsplit;
@@ -169,7 +170,7 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
   w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = nullptr;
-  w.s32 = w.stat = w.st_m = w.st_l = w.ginv = nullptr;
+  w.s32 = w.stat = w.gfac = w.st_m = w.st_l = w.ginv = nullptr;
   w.gexp = nullptr;
   if (h->ncross > 0 && use_fold(h, Kv) && fold_streams(h, Kv)) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv), sld = fold_stream_stat_ld((int)kvp);
@@ -188,6 +189,7 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
     const bool split = R == 384 && h->sc_tile == 5 && h->split_softmax;   // then the scores never exist in fp32
     if (!split) w.s32 = cv.take<float>((size_t)N * R * kvp);
     w.stat = cv.take<float>((size_t)2 * N * R * ((Kv + 175) / 176));
+    if (split && fold_inreg_rescale(h)) w.gfac = cv.take<float>((size_t)N * ((Kv + 175) / 176) * 512);
     w.p16 = cv.take<char>((size_t)N * R * kvp, 2);
     w.u16 = cv.take<char>((size_t)N * R * E, 2);
   } else {
@@ -556,8 +558,15 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
           sc.stat_m = w.stat; sc.stat_l = w.stat + (size_t)N * R * ntiles;
           rc = launch_gemm(&sc, 1, EPI_SOFTPART, op, stream);
           if (rc) return chk(rc, "fold scores gemm (softmax partials)");
-          rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);
-          if (rc) return chk(rc, "fold softmax rescale");
+          if (w.gfac) {
+            // second half of the softmax without a pass over P: only the row factors are computed here, the P . enc GEMM applies them
+            // to its P~ fragments in registers (same arithmetic, same rounding as the rescale pass)
+            rc = launch_fold_rowfactor(sc.stat_m, sc.stat_l, w.gfac, N * R, R, ntiles, stream);
+            if (rc) return chk(rc, "fold row factors");
+          } else {
+            rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);
+            if (rc) return chk(rc, "fold softmax rescale");
+          }
         } else {
           sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;   // fp32 rows
           rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
@@ -577,6 +586,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
         pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N;
         pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
+        if (w.gfac && sc.tile_cfg == 5 && h->split_softmax) { pv.pscale = w.gfac; pv.ps_ntiles = (kv + 175) / 176; }
         rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold p.enc gemm");
         }
@@ -734,11 +744,12 @@ int mra_qformer_prepare(mra_qformer* h, void* stream) {
 
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode) {
   if (!h) return fail(MRA_EINVAL, "null handle");
-  if (mode < 0 || mode > 4)
-    return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache), 2 (folded), 3 (folded, 128x384 loader-wave tiles) or 4 (folded, streaming kernels)");
+  if (mode < 0 || mode > 5)
+    return fail(MRA_EINVAL, "cross mode must be 0 (automatic), 1 (K/V cache), 2 (folded), 3 (folded, 128x384 loader-wave tiles), 4 (folded, streaming kernels) or 5 (folded, separate rescale pass)");
   h->cross_mode = mode >= 3 ? 2 : mode;
   h->fold_tile = mode == 3 ? 4 : 2;
   h->fold_stream = mode == 4;     // measured 13 % slower than the loader-wave GEMMs + rescale pass: opt-in
+  h->inreg_rescale = mode != 5;   // 5: the round-1 form with a rescale pass over P between the two big GEMMs, kept as the measured alternative
   return MRA_OK;
 }
 

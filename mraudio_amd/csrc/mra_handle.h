@@ -89,9 +89,10 @@ struct mra_qformer {
   // folded cross-attention (mra_qformer_set_cross_mode): per cross layer the key weight regrouped as [heads][E][64]
   char* arena_f = nullptr;
   bool fold_stale = true;
-  bool split_softmax = true;                      // scores GEMM writes exp2(s - tile max) + tile statistics (MRA_SPLIT_SOFTMAX=0: fp32 rows)
-  int sc_tile = 5;                                // scores: 5 = the 176 x 384 tile (MRA_SC_TILE=2: 128 x 128)
-  bool pv_kmajor = true;                          // P . enc reads the encoder tokens themselves (K-major weights, no enc^T copy); MRA_PV_KMAJOR=0
+  bool split_softmax = true;                      // scores GEMM writes exp2(s - tile max) + tile statistics (false: fp32 rows + row softmax)
+  bool inreg_rescale = true;                      // split softmax: the P . enc GEMM applies the row factors to its P~ fragments (false: a rescale pass over P; cross mode 5)
+  int sc_tile = 5;                                // scores: 5 = the 176 x 384 tile
+  bool pv_kmajor = true;                          // P . enc reads the encoder tokens themselves (K-major weights, no enc^T copy)
   int pv_tile = 5;                                // P . enc: 5 = the 176 x 384 loader-wave tile (one workgroup per CU at E = 1408)
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
   bool fold_stream = false;                       // folded path on the streaming kernels of fold_stream.hip (mra_qformer_set_cross_mode 4)
@@ -119,6 +120,8 @@ inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 |
 inline bool fold_kmajor(const mra_qformer* h) {
   return h->pv_kmajor && h->pv_tile == 5 && h->cfg.heads * h->cfg.n_query == 384 && h->cfg.enc_width % 176 == 0;
 }
+// split softmax without the rescale pass: needs the 176-column score tiles and the K-major 176 x 384 P . enc tile
+inline bool fold_inreg_rescale(const mra_qformer* h) { return h->inreg_rescale && h->split_softmax && h->sc_tile == 5 && fold_kmajor(h); }
 inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 127) / 128 * 128; }
 // the streaming kernels (fold_stream.hip): f16 operands, 384 (head, query) rows, E a multiple of 176
 inline bool fold_streams(const mra_qformer* h, int kv) {

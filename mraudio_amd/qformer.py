@@ -360,7 +360,7 @@ class QFormer(nn.Module):
         """How the cross-attention layers run: ``"auto"`` (folded from Kv >= 2048), ``"kv_cache"``, ``"fold"``, or the
         A/B formulations ``"fold384"`` (128 x 384 tiles) / ``"fold_stream"`` (streaming kernels, f16 only)
         (``mra_qformer_set_cross_mode``).  Same arithmetic, re-associated; the workspace size follows the mode."""
-        code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4}.get(mode, mode)
+        code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4, "fold_rescale_pass": 5}.get(mode, mode)
         check(lib().mra_qformer_set_cross_mode(self._handle, int(code)), "mra_qformer_set_cross_mode")
 
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:

@@ -85,6 +85,13 @@ static void fold_ab(int rounds) {
   const double o_s = timed([&] { launch_gemm(&sc, 1, EPI_SOFTPART, OP_F16, 0); });
   const double o_r = timed([&] { launch_softmax_rescale(P, kvp, M, L, items * R, nt, 176, kvp, OP_F16, 0); });
   const double o_p = timed([&] { launch_gemm(&pv, 1, EPI_OP, OP_F16, 0); });
+  // the rescale pass folded into P . enc: row factors from a small kernel, applied to the P~ fragments in registers
+  float* F;
+  CK(hipMalloc((void**)&F, (size_t)items * nt * 512 * 4));
+  const double o_f = timed([&] { launch_fold_rowfactor(M, L, F, items * R, R, nt, 0); });
+  pv.pscale = F; pv.ps_ntiles = nt;
+  const double o_ps = timed([&] { launch_gemm(&pv, 1, EPI_OP, OP_F16, 0); });
+  printf("in-register rescale: row factors %.3f ms + pv %.3f ms (against rescale pass %.3f + pv %.3f)\n", o_f, o_ps, o_r, o_p);
   const double fl = 2.0 * items * R * (double)kv * E;
   printf("fold A/B (ms, executed TF/s): streaming scores+stats %.3f (%.0f)  pv %.3f (%.0f)  both %.3f | loader-wave scores %.3f (%.0f)  rescale %.3f  pv %.3f (%.0f)  sum %.3f\n",
          t_s, fl / t_s / 1e9, t_p, fl / t_p / 1e9, t_b, o_s, fl / o_s / 1e9, o_r, o_p, fl / o_p / 1e9, o_s + o_r + o_p);

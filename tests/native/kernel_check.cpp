@@ -377,6 +377,49 @@ static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   report(name, worst, 2e-4);
 }
 
+// P . enc with the row factors of the split softmax applied inside the GEMM (GemmProb::pscale): against the rescale-pass arithmetic --
+// P[m][k] = op(float(P~[m][k]) * g[tile(k)][m]), then the product in double.  The tail of A past ntiles * 176 holds NaN patterns: it must read as zero.
+static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
+  gemm_force_config(-1);
+  const int ntiles = (kv + 175) / 176, K = ((std::max((kv + 127) / 128 * 128, ntiles * 176) + 127) / 128) * 128, ldw = N;
+  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * kv * ldw);
+  std::vector<float> G((size_t)batch * ntiles * 512, 123.f);
+  for (size_t b = 0; b < (size_t)batch; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k) A[(b * M + m) * K + k] = k < kv ? to_op(fabsf(frand()), op) : (k < ntiles * 176 ? to_op(0.f, op) : (uint16_t)0x7fff);
+  for (auto& v : W) v = to_op(frand(0.5f), op);
+  for (size_t b = 0; b < (size_t)batch; ++b)
+    for (int t = 0; t < ntiles; ++t)
+      for (int m = 0; m < M; ++m) G[(b * ntiles + t) * 512 + m] = expf(-4.f * fabsf(frand())) * (t % 3 == 2 ? 1e-6f : 1.f);
+  Dev<uint16_t> dA(A), dW(W), dC((size_t)batch * M * N);
+  Dev<float> dG(G);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.C = dC.p; p.c = RowView{0, M, N};
+  p.M = M; p.N = N; p.K = K; p.batch = batch; p.a_bs = (long long)M * K; p.w_bs = (long long)kv * ldw; p.c_bs_bytes = (long long)M * N * 2;
+  p.w_ld = ldw; p.k_rows = kv; p.tile_cfg = 5; p.pscale = dG.p; p.ps_ntiles = ntiles;
+  const int rc = launch_gemm(&p, 1, EPI_OP, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> c = dC.get();
+  double worst = rc ? 1e30 : 0;
+  for (int b = 0; b < batch && !rc; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; n += 7) {
+        double acc = 0;
+        for (int k = 0; k < kv; ++k) {
+          const float gk = G[((size_t)b * ntiles + k / 176) * 512 + m];   // f16: the kernel rounds the factor to f16 first (packed multiplies)
+          const float pr = from_op(to_op(from_op(A[((size_t)b * M + m) * K + k], op) * (op == OP_F16 ? from_op(to_op(gk, op), op) : gk), op), op);
+          acc += (double)pr * from_op(W[((size_t)b * kv + k) * ldw + n], op);
+        }
+        const double got = from_op(c[((size_t)b * M + m) * N + n], op);
+        const double err = fabs(got - acc) / (1 + fabs(acc));
+        worst = std::isfinite(err) ? std::max(worst, err) : 1e30;
+      }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm K-major W + row factors %s M%d N%d kv%d (K %d) x%d", op == OP_F16 ? "f16" : "bf16", M, N, kv, K, batch);
+  report(name, worst, op == OP_F16 ? 2e-3 : 1.2e-2);
+}
+
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
   gemm_force_config(-1);
@@ -969,6 +1012,9 @@ int main(int argc, char** argv) {
   test_gemm_kmajor(OP_F16, 384, 352, 320, 300, 2);                  // P . enc with the weights K-major (transposed LDS reads)
   test_gemm_kmajor(OP_F16, 200, 176, 64, 64, 3);
   test_gemm_kmajor(OP_BF16, 384, 528, 192, 150, 1);
+  test_gemm_pscale(OP_F16, 384, 352, 1000, 2);                      // 6 score tiles, K 1152: the factor ring wraps, NaN tail
+  test_gemm_pscale(OP_F16, 384, 176, 150, 3);
+  test_gemm_pscale(OP_BF16, 200, 176, 700, 1);
   test_gemm_batched(4, EPI_F32, OP_F16, 100, 177, 64, 2, true);
   test_fold_stream(2, 300, 704, 1.f);       // two score tiles, ragged kv, two E slabs
   test_fold_stream(1, 2100, 704, 1.f);      // 12 score tiles, K loop of 34 steps (not a multiple of the set rotation)

@@ -11,7 +11,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python3 - <<PY
 import csv, glob, collections, json
-keys = {"Li5ELb0ELi176ELi384ELi8E": "scores_gemm", "Li0ELb0ELi176ELi384ELi8E": "p_enc_gemm", "softmax_rescale": "softmax_rescale",
+keys = {"Li5ELb0ELi176ELi384ELi8E": "scores_gemm", "Li0ELb0ELi176ELi384ELi8E": "p_enc_gemm", "softmax_rescale": "softmax_rescale", "fold_rowfactor": "row_factors",
         "transpose_pad64": "enc_transpose", "Li64ELi64ELi2ELi2ELi0E": "small_gemm_epi_op"}
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*counter_collection.csv"):
