@@ -420,6 +420,57 @@ static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
   report(name, worst, op == OP_F16 ? 2e-3 : 1.2e-2);
 }
 
+// scores of the folded path: batched, ragged N, EPI_SOFTPART -- P~[m][n] = exp2(alpha s - tile max) in the operand dtype, tile maxima and
+// tile sums (of the ROUNDED P~); columns past N inside the last tile are zero.
+static void test_gemm_softpart(int op, int M, int kv, int K, int batch) {
+  gemm_force_config(-1);
+  const int ntiles = (kv + 175) / 176, ldp = ntiles * 176 + 16;
+  const float alpha = 0.125f * 1.4426950408889634f;
+  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * kv * K);
+  for (auto& v : A) v = to_op(frand(), op);
+  for (auto& v : W) v = to_op(frand(), op);
+  Dev<uint16_t> dA(A), dW(W), dP((size_t)batch * M * ldp);
+  Dev<float> dM((size_t)batch * M * ntiles), dL((size_t)batch * M * ntiles);
+  dP.fill(0xFF);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA.p; p.a = RowView{0, M, K}; p.a_bs = (long long)M * K; p.W = dW.p; p.w_bs = (long long)kv * K;
+  p.M = M; p.N = kv; p.K = K; p.batch = batch; p.n_ragged = 1; p.tile_cfg = 5;
+  p.C = dP.p; p.c = RowView{0, M, ldp}; p.c_bs_bytes = (long long)M * ldp * 2; p.alpha = alpha; p.stat_m = dM.p; p.stat_l = dL.p;
+  const int rc = launch_gemm(&p, 1, EPI_SOFTPART, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> P = dP.get();
+  std::vector<float> sm = dM.get(), sl = dL.get();
+  double worst = rc ? 1e30 : 0;
+  std::vector<double> srow(ntiles * 176);
+  for (int b = 0; b < batch && !rc; ++b)
+    for (int m = 0; m < M; ++m) {
+      for (int n = 0; n < kv; ++n) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)from_op(A[((size_t)b * M + m) * K + k], op) * from_op(W[((size_t)b * kv + n) * K + k], op);
+        srow[n] = acc * alpha;
+      }
+      for (int t = 0; t < ntiles; ++t) {
+        const int lo = t * 176, hi = std::min(kv, lo + 176);
+        double mx = -1e300, l = 0;
+        for (int n = lo; n < hi; ++n) mx = std::max(mx, srow[n]);
+        const size_t si = ((size_t)b * M + m) * ntiles + t;
+        worst = std::max(worst, fabs(sm[si] - mx) / (1 + fabs(mx)));
+        for (int n = lo; n < lo + 176; ++n) {
+          const double got = from_op(P[((size_t)b * M + m) * ldp + n], op);
+          const double want = n < hi ? exp2(srow[n] - sm[si]) : 0.0;     // relative to the kernel's own maximum
+          l += got;
+          const double err = fabs(got - want);
+          worst = std::isfinite(err) ? std::max(worst, err) : 1e30;
+        }
+        worst = std::max(worst, fabs(sl[si] - l) / (1 + fabs(l)) * 10);   // the sum is of the rounded values: tight
+      }
+    }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm softmax-partial %s M%d kv%d K%d x%d", op == OP_F16 ? "f16" : "bf16", M, kv, K, batch);
+  report(name, worst, op == OP_F16 ? 2e-3 : 1.2e-2);
+}
+
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
   gemm_force_config(-1);
@@ -1012,6 +1063,10 @@ int main(int argc, char** argv) {
   test_gemm_kmajor(OP_F16, 384, 352, 320, 300, 2);                  // P . enc with the weights K-major (transposed LDS reads)
   test_gemm_kmajor(OP_F16, 200, 176, 64, 64, 3);
   test_gemm_kmajor(OP_BF16, 384, 528, 192, 150, 1);
+  test_gemm_softpart(OP_F16, 384, 1000, 192, 4);
+  test_gemm_softpart(OP_F16, 384, 530, 64, 3);
+  test_gemm_softpart(OP_BF16, 384, 400, 128, 2);
+  test_gemm_softpart(OP_F16, 200, 1000, 320, 2);                   // M < 384: clamped rows
   test_gemm_pscale(OP_F16, 384, 352, 1000, 2);                      // 6 score tiles, K 1152: the factor ring wraps, NaN tail
   test_gemm_pscale(OP_F16, 384, 176, 150, 3);
   test_gemm_pscale(OP_BF16, 200, 176, 700, 1);
