@@ -42,8 +42,14 @@ constexpr float LOG2E = 1.4426950408889634f;
 // two transposed LDS reads (ds_read_b64_tr_b16) of V [key][d].
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATT_WAVES = 9;
-template <typename T>
-__global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, T* ctx, int S, int heads, int hd, float sl2) {
+// The softmax is VALU-bound next to 108 MFMAs per 16-query block (72 scores per lane), so it is kept lean: the scale rides the
+// exponent's fma; with the sequence length known at compile time (SC = 257 for ViT-g/224) only key fragment 16 is masked and
+// fragment 17 (all padding) is neither multiplied nor exponentiated; and the row sum comes out of the P V MFMAs themselves:
+// V's first padding column (d = hd) is set to one when the head is staged, so O^T[hd][query] = sum of the ROUNDED P row.
+template <typename T, int SC>
+__global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, T* ctx, int S_rt, int heads, int hd, float sl2) {
+  const int S = SC ? SC : S_rt;
+  const bool ones = hd < HD_PAD;    // a padding column exists: the row sum rides the MFMAs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + KS_PAD * KV_PITCH;
@@ -73,6 +79,11 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kr[u][e] = from_f32<T>(0.f); vr[u][e] = kr[u][e]; }
       }
+      if (ones && ch == (hd >> 3)) {   // the ones column (masked keys carry P = 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e == (hd & 7)) vr[u][e] = from_f32<T>(1.f);
+      }
       if (c < KS_PAD * 12) {
         *reinterpret_cast<V8*>(Ks + row * KV_PITCH + ch * 16) = kr[u];
         *reinterpret_cast<V8*>(Vs + row * KV_PITCH + ch * 16) = vr[u];
@@ -91,34 +102,42 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 32 * ks);
     }
+    constexpr int NFR = SC ? (SC + 15) / 16 : KS_PAD / 16;   // key fragments with at least one valid key (compile-time S)
     f32x4 sc[KS_PAD / 16];
-    float mx = -3.0e38f;
+    float mx = -3.0e38f;     // of the raw scores: sl2 > 0
 #pragma unroll
     for (int i = 0; i < KS_PAD / 16; ++i) {
+      if (i >= NFR) { sc[i] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; continue; }
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const V8 kf = *reinterpret_cast<const V8*>(Ks + (16 * i + lm) * KV_PITCH + (4 * ks + lc) * 16);
         a = mfma16<T>(kf, qf[ks], a);
       }
+      if (SC && 16 * i + 16 <= SC) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = 16 * i + 4 * lc + e < S ? a[e] * sl2 : -3.0e38f;
-        mx = fmaxf(mx, a[e]);
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, a[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (16 * i + 4 * lc + e >= S) a[e] = -3.0e38f;
+          mx = fmaxf(mx, a[e]);
+        }
       }
       sc[i] = a;
     }
-    // Scheduling of the 54 K-fragment reads against the 54 MFMAs: six reads run ahead, then one read per MFMA.  Left alone
+    // Scheduling of the K-fragment reads against the MFMAs: six reads run ahead, then one read per MFMA.  Left alone
     // the scheduler hoists every read above the first MFMA and the allocator spills (644 bytes of scratch per lane, 0.96 ms per
     // layer); strictly one read per MFMA exposes the LDS latency on every MFMA (0.37 ms).
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-    for (int i = 0; i < 3 * KS_PAD / 16; ++i) {
+    for (int i = 0; i < 3 * NFR; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * sl2;
     float l = 0.f;
     // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]
     f32x4 ot[HD_PAD / 16];
@@ -129,9 +148,9 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
       V8 pf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pf[e] = from_f32<T>(__builtin_amdgcn_exp2f(sc[2 * ks][e] - mx));          // masked keys: exp2(-huge) = 0
-        pf[4 + e] = from_f32<T>(__builtin_amdgcn_exp2f(sc[2 * ks + 1][e] - mx));
-        l += (float)pf[e] + (float)pf[4 + e];
+        pf[e] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * ks][e], sl2, -mxs)));          // masked keys: exp2(-huge) = 0
+        pf[4 + e] = 2 * ks + 1 < NFR ? from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * ks + 1][e], sl2, -mxs))) : from_f32<T>(0.f);
+        if (!ones) l += (float)pf[e] + (float)pf[4 + e];
       }
       // V^T fragment of d block df in the same key order: transposed 4 x 16 blocks at keys 32 ks + 4 lc and 32 ks + 16 + 4 lc
       const char* vb = Vs + (32 * ks + 4 * lc + (lm >> 2)) * KV_PITCH + (lane & 3) * 8;
@@ -149,8 +168,19 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    if (ones) {
+      // O^T[hd][query]: fragment hd / 16, row hd % 16 = 4 c + e
+      float lo = 0.f;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (df == (hd >> 4) && e == (hd & 3)) lo = ot[df][e];
+      l = __shfl(lo, ((hd & 15) >> 2) * 16 + lm);
+    } else {
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+    }
     const float inv = 1.0f / l;
     if (q0 + lm < S) {
       T* crow = ctx + ((long long)frame * S + q0 + lm) * (heads * hd) + head * hd;
@@ -419,8 +449,10 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
   const size_t attn_lds = 2 * KS_PAD * KV_PITCH;
   static unsigned long long attr_done = 0;
   if (!(attr_done >> (h->device & 63) & 1)) {
-    if (hipFuncSetAttribute((const void*)vit_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)vit_attn_kernel<f16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_kernel<f16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess)
       return fail(MRA_EHIP, "hipFuncSetAttribute(vit_attn_kernel)");
     attr_done |= 1ull << (h->device & 63);
   }
@@ -436,8 +468,13 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       rc = launch_gemm(&p, 1, EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
-    if (op == OP_F16) hipLaunchKernelGGL(vit_attn_kernel<f16>, dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
-    else hipLaunchKernelGGL(vit_attn_kernel<bf16>, dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
+    if (S == 257) {   // ViT-g/224: the sequence length as a compile-time constant
+      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
+    } else {
+      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
+    }
     {
       GemmProb p{};
       p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;

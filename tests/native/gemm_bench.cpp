@@ -147,8 +147,63 @@ static void order_ab(int rounds) {
   gemm_set_tile_order(0);
 }
 
+// would split-K pay on the layer chain's residual GEMMs?  One problem over the whole K against two problems over half of it each
+// (a two-problem launch: exactly the work of a 2-way split, partial sums to two fp32 outputs).
+static void splitk_ab(int rounds) {
+  const int M = 2048, N = 768;
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)M * 3072);
+  for (auto& v : h) v = (_Float16)d(rng);
+  _Float16 *A, *W;
+  float *C, *R, *bias;
+  CK(hipMalloc((void**)&A, h.size() * 2)); CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&W, h.size() * 2)); CK(hipMemcpy(W, h.data(), (size_t)N * 3072 * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C, (size_t)4 * M * N * 4)); CK(hipMalloc((void**)&R, (size_t)M * N * 4)); CK(hipMemset(R, 0, (size_t)M * N * 4));
+  CK(hipMalloc((void**)&bias, N * 4)); CK(hipMemset(bias, 0, N * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timed = [&](auto&& fn) {
+    double best = 1e30;
+    for (int r = 0; r < rounds; ++r) {
+      fn();
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; ++i) fn();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, (double)ms / 20);
+    }
+    return best * 1e3;
+  };
+  for (int K : {768, 3072}) {
+    for (int rows : {1024, 2048}) {
+      GemmProb p{};
+      p.A = A; p.a = RowView{0, rows, K}; p.W = W; p.bias = bias; p.R = R; p.r = RowView{0, rows, N}; p.C = C; p.c = RowView{0, rows, N};
+      p.M = rows; p.N = N; p.K = K;
+      if (K == 3072) p.tile_cfg = 6;
+      const double whole = timed([&] { launch_gemm(&p, 1, EPI_RES_F32, OP_F16, 0); });
+      // halves: A row stride K, but only K / 2 columns are walked -> RowView.ld = K with p.K = K / 2; W needs its own row stride: use two
+      // weight matrices of K / 2 columns (same bytes walked)
+      GemmProb q[2];
+      for (int s = 0; s < 2; ++s) {
+        q[s] = GemmProb{};
+        q[s].A = A + s * (K / 2); q[s].a = RowView{0, rows, K}; q[s].W = W + (size_t)s * N * (K / 2); q[s].C = C + (size_t)(1 + s) * rows * N; q[s].c = RowView{0, rows, N};
+        q[s].M = rows; q[s].N = N; q[s].K = K / 2;
+        if (K == 3072) q[s].tile_cfg = 6;
+      }
+      const double halves = timed([&] { launch_gemm(q, 2, EPI_F32, OP_F16, 0); });
+      q[0].tile_cfg = q[1].tile_cfg = 0;
+      const double halves_auto = timed([&] { launch_gemm(q, 2, EPI_F32, OP_F16, 0); });
+      printf("rows %d K %d: whole %.1f us   two halves %.1f us (auto tile %.1f us)\n", rows, K, whole, halves, halves_auto);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "splitk")) { splitk_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "order")) { order_ab(rounds); return 0; }
   const int only = argc > 2 ? atoi(argv[2]) : -1;      // run a single shape (profiling)

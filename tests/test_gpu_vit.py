@@ -108,3 +108,20 @@ def test_raw_frames_through_the_model_use_the_batched_hip_encoder(dev):
     assert (out["z"]["video"] - want["z"]["video"]).abs().max().item() < 2e-2
     scale = want["fused"].abs().max().item()
     assert (out["fused"] - want["fused"]).abs().max().item() <= 2e-3 * scale
+
+
+def test_other_frame_sizes_take_the_generic_attention_kernel(dev):
+    """224 x 224 frames (257 tokens) run the attention core specialised on the sequence length; any other geometry takes the
+    generic instantiation (run-time masks, every key fragment): 112 x 112 -> 65 tokens, 154 x 154 -> 122 tokens (a partially
+    valid key fragment), against the fp32 restatement with the same weights."""
+    for img, seed in ((112, 21), (154, 22)):
+        ref = EvaViTg(img_size=img, depth=2).eval().init_seeded_(seed)
+        hip = HipEvaViTg(img_size=img, depth=2, device=dev).eval()
+        hip.load_state_dict(ref.state_dict())
+        x = torch.randn(3, 3, img, img, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            want = ref(x)
+            got = hip(x.to(dev)).float().cpu()
+        assert got.shape == want.shape == (3, (img // 14) ** 2 + 1, 1408)
+        err = (got - want).abs()
+        assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (img, err.max().item(), err.mean().item())
