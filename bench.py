@@ -195,9 +195,10 @@ def main():
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
-    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
+    # PMC passes of the build in force: the in-register rescale (default) or the separate rescale pass (cross mode 5 = the r02 mid-round build)
+    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r02b_pmc_fold.json")
     if not os.path.exists(fold_pmc):
-        fold_pmc = os.path.join(ROOT, "profiles", "r01o_pmc_fold.json")
+        fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
     traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
     if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")

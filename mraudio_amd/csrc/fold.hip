@@ -123,9 +123,13 @@ __global__ void __launch_bounds__(256) softmax_rescale_kernel(T* P, long long ld
 
 // The same row statistics as softmax_rescale_kernel, but only the factors leave: one wave per row, factors in the [item][tile][512] layout
 // the P . enc GEMM's loader waves copy into LDS one tile slice (2 KB) at a time.
-__global__ void __launch_bounds__(256) fold_rowfactor_kernel(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles) {
+// It also zeroes the row's P~ columns from ntiles * tile_cols to kvp, which the scores GEMM never writes and the P . enc GEMM reads
+// (its K runs to kvp): zero times any finite factor is zero, so that GEMM needs no column test of its own.
+__global__ void __launch_bounds__(256) fold_rowfactor_kernel(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles,
+                                                             unsigned short* P, long long ld_p, int tile_cols, int kvp) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
+  for (int c = ntiles * tile_cols + lane; c < kvp; c += 64) P[(long long)row * ld_p + c] = 0;
   const float* sm = stat_m + (long long)row * ntiles;
   const float* sl = stat_l + (long long)row * ntiles;
   float m = -3.0e38f;
@@ -208,10 +212,12 @@ int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p,
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-int launch_fold_rowfactor(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles, hipStream_t stream) {
+int launch_fold_rowfactor(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles, void* P, long long ld_p, int tile_cols,
+                          int kvp, hipStream_t stream) {
   if (rows <= 0) return 0;
-  if (ntiles <= 0 || R <= 0 || R > 512 || rows % R) return -1;
-  hipLaunchKernelGGL(fold_rowfactor_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, stat_m, stat_l, factors, rows, R, ntiles);
+  if (ntiles <= 0 || R <= 0 || R > 512 || rows % R || !P || ld_p < kvp || ntiles * tile_cols > kvp) return -1;
+  hipLaunchKernelGGL(fold_rowfactor_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, stat_m, stat_l, factors, rows, R, ntiles, (unsigned short*)P, ld_p,
+                     tile_cols, kvp);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -487,8 +487,8 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
       if constexpr (PSC) {
         if (wave != 8) return;
         const int t_hi = (kt * BK + BK - 1) / PS_TILE;
-        for (; gt_next <= t_hi && gt_next < P.ps_ntiles; ++gt_next) {
-          const char* sg = (const char*)(P.pscale + (long long)gt_next * 512) + lane * 16;
+        for (; gt_next <= t_hi; ++gt_next) {   // past the last tile: its factors again (finite; the P~ columns there are zero)
+          const char* sg = (const char*)(P.pscale + (long long)min(gt_next, P.ps_ntiles - 1) * 512) + lane * 16;
           char* dg = smem + GT_OFF + (gt_next & 3) * GT_SLICE;
           glds16(sg, dg);
           glds16(sg + 1024, dg + 1024);
@@ -554,14 +554,10 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
           if constexpr (sizeof(T) == 2 && __is_same(T, f16)) {
             // packed f16 multiplies (4 per fragment) with the factor rounded to f16: the fp32 form of the rescale pass costs 28 VALU
             // instructions per fragment and made this load-bound kernel compute-bound (0.236 -> 0.288 ms)
-            const typename Vec8<T>::type prod = b[j] * (f16)gf;
-            typename Vec8<T>::type zero;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) zero[e] = (f16)0.f;
-            b[j] = t < P.ps_ntiles ? prod : zero;
+            b[j] = b[j] * (f16)gf;
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b[j][e] = t < P.ps_ntiles ? from_f32<T>((float)b[j][e] * gf) : from_f32<T>(0.f);
+            for (int e = 0; e < 8; ++e) b[j][e] = from_f32<T>((float)b[j][e] * gf);
           }
         }
       }

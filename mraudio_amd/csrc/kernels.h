@@ -66,8 +66,9 @@ struct GemmProb {
   float* stat_m;
   float* stat_l;
   // pscale != nullptr (176 x 384 loader-wave tile with K-major W only): the A operand is the unnormalised P~ of the split softmax; A[m][k]
-  // is multiplied by pscale[((batch entry * ps_ntiles) + k / 176) * 512 + m] in fp32 and rounded to the operand dtype on its way into
-  // the MFMA (what the separate rescale pass did in HBM); k >= ps_ntiles * 176 reads as zero.  M <= 512.
+  // is multiplied by pscale[((batch entry * ps_ntiles) + min(k / 176, ps_ntiles - 1)) * 512 + m] on its way into the MFMA (f16: packed
+  // multiplies with the factor rounded to f16; bf16: in fp32, rounded once -- what the separate rescale pass did in HBM).  A must be
+  // ZERO from column ps_ntiles * 176 on (launch_fold_rowfactor does that).  M <= 512.
   const float* pscale;
   int ps_ntiles;
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
@@ -166,8 +167,10 @@ int launch_softmax_rows(const float* S, long long ld_s, void* P, long long ld_p,
 // second half of the split softmax (first half: EPI_SOFTPART of the scores GEMM): row statistics over the column tiles,
 // then P[row][k] *= exp2(m_tile - m_row) / sum in place; columns [kv_cols, kvp) are zeroed.  tile_cols = columns per tile.
 // split softmax, second half without a pass over P: factors[(row / R * ntiles + t) * 512 + row % R] = exp2(m_tile - m_row) / L_row from the
-// tile statistics stat_*[row * ntiles + t] (rows = items * R, R <= 512); read by the P . enc GEMM through GemmProb::pscale
-int launch_fold_rowfactor(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles, hipStream_t stream);
+// tile statistics stat_*[row * ntiles + t] (rows = items * R, R <= 512); read by the P . enc GEMM through GemmProb::pscale.  Also zeroes
+// the 16-bit P~ rows (row stride ld_p elements) from column ntiles * tile_cols to kvp, which the scores GEMM leaves unwritten.
+int launch_fold_rowfactor(const float* stat_m, const float* stat_l, float* factors, int rows, int R, int ntiles, void* P, long long ld_p, int tile_cols,
+                          int kvp, hipStream_t stream);
 int launch_softmax_rescale(void* P, long long ld_p, const float* stat_m, const float* stat_l, int rows, int ntiles, int tile_cols, int kvp,
                            int op_dtype, hipStream_t stream);
 // dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < ld_d; src [batch][R][C], dst [batch][C][ld_d]

@@ -561,7 +561,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
           if (w.gfac) {
             // second half of the softmax without a pass over P: only the row factors are computed here, the P . enc GEMM applies them
             // to its P~ fragments in registers (same arithmetic, same rounding as the rescale pass)
-            rc = launch_fold_rowfactor(sc.stat_m, sc.stat_l, w.gfac, N * R, R, ntiles, stream);
+            rc = launch_fold_rowfactor(sc.stat_m, sc.stat_l, w.gfac, N * R, R, ntiles, w.p16, kvp, 176, kvp, stream);
             if (rc) return chk(rc, "fold row factors");
           } else {
             rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);

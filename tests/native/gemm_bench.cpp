@@ -88,7 +88,7 @@ static void fold_ab(int rounds) {
   // the rescale pass folded into P . enc: row factors from a small kernel, applied to the P~ fragments in registers
   float* F;
   CK(hipMalloc((void**)&F, (size_t)items * nt * 512 * 4));
-  const double o_f = timed([&] { launch_fold_rowfactor(M, L, F, items * R, R, nt, 0); });
+  const double o_f = timed([&] { launch_fold_rowfactor(M, L, F, items * R, R, nt, P, kvp, 176, kvp, 0); });
   pv.pscale = F; pv.ps_ntiles = nt;
   const double o_ps = timed([&] { launch_gemm(&pv, 1, EPI_OP, OP_F16, 0); });
   printf("in-register rescale: row factors %.3f ms + pv %.3f ms (against rescale pass %.3f + pv %.3f)\n", o_f, o_ps, o_r, o_p);

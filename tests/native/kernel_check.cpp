@@ -378,7 +378,8 @@ static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
 }
 
 // P . enc with the row factors of the split softmax applied inside the GEMM (GemmProb::pscale): against the rescale-pass arithmetic --
-// P[m][k] = op(float(P~[m][k]) * g[tile(k)][m]), then the product in double.  The tail of A past ntiles * 176 holds NaN patterns: it must read as zero.
+// P[m][k] = op(float(P~[m][k]) * g[tile(k)][m]), then the product in double.  A is zero from column kv on; the factor slots past the last tile
+// reuse its (finite) factors.
 static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
   gemm_force_config(-1);
   const int ntiles = (kv + 175) / 176, K = ((std::max((kv + 127) / 128 * 128, ntiles * 176) + 127) / 128) * 128, ldw = N;
@@ -386,7 +387,7 @@ static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
   std::vector<float> G((size_t)batch * ntiles * 512, 123.f);
   for (size_t b = 0; b < (size_t)batch; ++b)
     for (int m = 0; m < M; ++m)
-      for (int k = 0; k < K; ++k) A[(b * M + m) * K + k] = k < kv ? to_op(fabsf(frand()), op) : (k < ntiles * 176 ? to_op(0.f, op) : (uint16_t)0x7fff);
+      for (int k = 0; k < K; ++k) A[(b * M + m) * K + k] = k < kv ? to_op(fabsf(frand()), op) : to_op(0.f, op);   // zero from column kv on (the caller's contract)
   for (auto& v : W) v = to_op(frand(0.5f), op);
   for (size_t b = 0; b < (size_t)batch; ++b)
     for (int t = 0; t < ntiles; ++t)

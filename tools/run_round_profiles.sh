@@ -1,5 +1,5 @@
 set -o pipefail
-O=gpurun_out/r02z
+O=gpurun_out/${1:-r02z}
 mkdir -p $O
 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 (cd tests/native && timeout -k 10 400 ./kernel_check quick > ../../$O/kernel_check.log 2>&1; tail -2 ../../$O/kernel_check.log)
@@ -7,6 +7,7 @@ python bench.py > $O/bench_line.json 2> $O/bench.err; tail -1 $O/bench.err
 python bench.py --workload ref --no-encode > $O/bench_ref_line.json 2>> $O/bench.err
 python tools/bench_finetune.py --steps 20 > $O/finetune_line.json 2>/dev/null
 python tools/bench_vit.py --frames 1024 --reps 2 > $O/vit_line.json 2>/dev/null
+python tools/bench_vit.py --frames 1024 --reps 2 --residual op >> $O/vit_line.json 2>/dev/null
 python tools/bench_vit.py --frames 1024 --reps 2 --backend torch >> $O/vit_line.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-encode --cpu-clips 0 > $O/prof_bench.log 2>&1
