@@ -165,7 +165,7 @@ def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
     t = h[:, 32]
     sim_ref, logit_ref = O.cosine_scores(h[:, :32], t)
     report = {}
-    for mode in ("fold", "fold_stream", "kv_cache"):
+    for mode in ("fold", "fold_rescale_pass", "fold_stream", "kv_cache"):
         qf.set_cross_mode(mode)
         res = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
         z, cls = res["query"].cpu(), res["cls"].cpu()
@@ -188,7 +188,7 @@ def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
             assert r["dlogit"] <= LOGIT_RTOL and r["dsim"] <= 2 * LOGIT_RTOL, (mode, kv, gain, r)
         else:
             assert r["rel"] < 6e-2, (mode, kv, gain, r)
-    for mode in ("fold", "fold_stream"):       # both split-softmax forms: rescale pass / power-of-two factors in registers
+    for mode in ("fold", "fold_rescale_pass", "fold_stream"):   # the split-softmax forms: row factors inside P.enc / rescale pass / power-of-two factors
         assert report[mode]["rel"] < 1.25 * report["kv_cache"]["rel"] + 5e-4, report
         assert report[mode]["dlogit"] < 1.5 * report["kv_cache"]["dlogit"] + 5e-4, report
 
