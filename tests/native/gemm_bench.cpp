@@ -103,6 +103,7 @@ static void order_ab(int rounds) {
       {"kvproj video 32x8224", 32 * 8224, 9216, 1408, EPI_KV, -1},
       {"vit qkv 263168x1408->4608", 1024 * 257, 4608, 1408, EPI_OP, -1},
       {"vit fc1 263168x1408->6144", 1024 * 257, 6144, 1408, EPI_GELU_OP, -1},
+      {"  same shape, plain epilogue", 1024 * 257, 6144, 1408, EPI_OP, -1},
       {"vit fc2 263168x6144->1408", 1024 * 257, 1408, 6144, EPI_F32, 3},
       {"vit proj 263168x1408->1408", 1024 * 257, 1408, 1408, EPI_F32, 3},
   };

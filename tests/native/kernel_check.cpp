@@ -1039,6 +1039,7 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1408, false);   // 256 x 256 tile with the GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
   gemm_set_tile_order(8);   // column-fastest panels (the ViT's N = 1408 GEMMs)
   test_gemm(2, EPI_RES_F32, OP_F16, 1300, 512, 320, true, 2);
