@@ -202,8 +202,56 @@ static void splitk_ab(int rounds) {
   }
 }
 
+// the layer chain's GEMM shapes on every small-tile configuration (GemmProb::tile_cfg 1 = 64 x 64, 2 = 128 x 128, 6 = 64 x 128 x 128-deep)
+static void chain_ab(int rounds) {
+  struct S { const char* name; int M, N, K, epi, groups; };
+  const S shapes[] = {{"qkv 2048x768->2304", 2048, 2304, 768, EPI_OP, 1},          {"attn-out 2048x768->768", 2048, 768, 768, EPI_RES_F32, 1},
+                      {"cross-q 1024x768->768", 1024, 768, 768, EPI_OP, 1},        {"cross-out 1024x768->768", 1024, 768, 768, EPI_RES_F32, 1},
+                      {"ffn-up 2 x 1024x768->3072", 1024, 3072, 768, EPI_GELU_OP, 2}, {"ffn-down 2 x 1024x3072->768", 1024, 768, 3072, EPI_RES_F32, 2}};
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)3072 * 3072);
+  for (auto& v : h) v = (_Float16)d(rng);
+  _Float16 *A, *W;
+  float *C, *R, *bias;
+  CK(hipMalloc((void**)&A, h.size() * 2)); CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&W, h.size() * 2 * 2)); CK(hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W + h.size(), h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C, (size_t)2 * 2048 * 3072 * 4)); CK(hipMalloc((void**)&R, (size_t)2048 * 768 * 4)); CK(hipMemset(R, 0, (size_t)2048 * 768 * 4));
+  CK(hipMalloc((void**)&bias, 4096 * 4)); CK(hipMemset(bias, 0, 4096 * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto& sh : shapes) {
+    printf("%-30s", sh.name);
+    for (int cfg : {1, 2, 6}) {
+      GemmProb q[2];
+      for (int g = 0; g < sh.groups; ++g) {
+        q[g] = GemmProb{};
+        q[g].A = A + (size_t)g * 1024 * sh.K; q[g].a = RowView{0, sh.M, sh.K}; q[g].W = W + (size_t)g * h.size(); q[g].bias = bias;
+        q[g].R = R; q[g].r = RowView{0, sh.M, sh.N}; q[g].C = (char*)C + (size_t)g * 2048 * 3072 * 2; q[g].c = RowView{0, sh.M, sh.N};
+        q[g].M = sh.M; q[g].N = sh.N; q[g].K = sh.K; q[g].tile_cfg = cfg;
+      }
+      if (cfg == 6 && sh.K % 128) { printf("  cfg6   n/a"); continue; }
+      double best = 1e30;
+      bool ok = true;
+      for (int r = 0; r < rounds && ok; ++r) {
+        if (launch_gemm(q, sh.groups, sh.epi, OP_F16, 0)) { ok = false; break; }
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) launch_gemm(q, sh.groups, sh.epi, OP_F16, 0);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, (double)ms / 20 * 1e3);
+      }
+      if (ok) printf("  cfg%d %5.1f us", cfg, best); else printf("  cfg%d refused", cfg);
+    }
+    printf("\n");
+  }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "chain")) { chain_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "splitk")) { splitk_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "order")) { order_ab(rounds); return 0; }
