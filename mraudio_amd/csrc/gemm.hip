@@ -610,6 +610,200 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
 }
 
 // =================================================================================================
+// 256x256x64, eight phases per pair of K tiles: 8 waves, both SIMD partners ping-pong between LDS reads + DMA issue and MFMAs
+// =================================================================================================
+// The schedule of cdna_hip_programming.md's "256^2 8-phase template", rebuilt from its rules (the example source is not in this
+// image).  8 waves = 2 (weight-row halves, wr) x 4 (activation-row quarters, wc), 128 x 64 outputs each; the two waves of a SIMD are
+// one of each wr and run one barrier apart (wr = 1 passes one barrier before the loop, wr = 0 one after it), so while one issues its 16
+// MFMAs of a phase the other reads the next fragments and issues its share of the DMA.
+// A K tile is staged as four 16 KB half-tiles, each read by EVERY wave in exactly one phase: W0 / W1 = the first / second 64 weight
+// rows of each wr, X0 / X1 = the first / second 32 activation rows of each wc.  Per K tile and wave:
+//   phase 1: read X0 (4 x b128), W0 (8)   MFMA W0 x X0        phase 3: read W1 (8, over W0)   MFMA W1 x X1
+//   phase 2: read X1 (4)                  MFMA W0 x X1        phase 4: --                     MFMA W1 x X0   (X0 kept in registers)
+// One half-tile (2 DMA instructions per wave) is staged per phase, as soon as its slot is dead: with E / O the even / odd LDS buffer,
+//   phase 1: W1(O, this pair's odd tile)   2: X0(E, +2)   3: W0(E, +2)   4: X1(E, +2)   5: W1(E, +2)   6: X0(O, +3)   7: W0(O, +3)   8: X1(O, +3)
+// and a counted vmcnt(6) in phases 4 and 8 leaves the three youngest half-tiles in flight: at phase 4 those are X1 / W0 / X0 of E(+2),
+// so all of O has landed (read in phases 5-7); at phase 8 X1 / W0 / X0 of O(+3), so all of E(+2) has (read in the next phases 1-3).
+// Reads of a retired buffer start one phase after the wait (every wave's wait + a barrier in between); a slot is restaged two
+// phases after its last read (X0: one phase after, its reads are retired by lgkmcnt(8) before phase 1's first barrier).
+// K / 64 must be even and >= 2.  Epilogues: those of the loader-wave kernel.
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
+  constexpr int TN = 256, TM = 256, BK = 64, ROWB = BK * 2, WGM = 4, WTN = 128, WTM = 64, FN = 8, FM = 4;
+  constexpr int HALF = 128 * ROWB, BUF = 4 * HALF;   // 16 KB half-tiles: W0, W1, X0, X1; 64 KB per K tile
+  constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int n0, m0;
+  const GemmProb& P = pick_tile<TN, TM>(args, n0, m0);
+  const int K = P.K, M = P.M;
+  const int nk = K / BK;
+
+  // DMA sources: half h, piece c (this lane's chunk q = tid + 512 c of the half's 1024): LDS row q >> 3, physical chunk q & 7
+  const char* src[4][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int q = tid + c * 512;
+    const int r = q >> 3, ch = (q & 7) ^ ((r >> 1) & 7);
+    const int w0row = (r < 64 ? r : 64 + r), w1row = w0row + 64;                 // rows 0-63 | 128-191, then 64-127 | 192-255
+    const int x0row = (r >> 5) * 64 + (r & 31), x1row = x0row + 32;              // 32 of every wc's 64
+    src[0][c] = (const char*)P.W + ((long long)min(n0 + w0row, P.N - 1) * K + ch * 8) * 2;
+    src[1][c] = (const char*)P.W + ((long long)min(n0 + w1row, P.N - 1) * K + ch * 8) * 2;
+    src[2][c] = (const char*)P.A + (view_off(P.a, min(m0 + x0row, M - 1)) + ch * 8) * 2;
+    src[3][c] = (const char*)P.A + (view_off(P.a, min(m0 + x1row, M - 1)) + ch * 8) * 2;
+  }
+  auto stage = [&](int buf, int h, int kt) {
+    char* base = smem + buf * BUF + h * HALF + wave * 1024;
+    const long long koff = (long long)kt * ROWB;
+    glds16(src[h][0] + koff, base);
+    glds16(src[h][1] + koff, base + 8192);
+  };
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int r = lane & 15;
+    const int c = (4 * ks + (lane >> 4)) ^ ((r >> 1) & 7);
+    foff[ks] = r * ROWB + c * 16;
+  }
+  const int wrow = wr * 64 * ROWB, xrow = wc * 32 * ROWB;   // this wave's rows inside a W / X half-tile
+
+  f32x4 acc[FN][FM];
+  if constexpr (EPI == EPI_RES_F32) {
+    accumulators_from_residual<FN, FM>(P, acc, n0 + wr * WTN, m0 + wc * WTM, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ordinary loads must not be pending once the DMA pipeline runs (the compiler drains everything at their first use)
+  } else {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  using V8 = typename Vec8<T>::type;
+  V8 wf[4][2], x0[2][2], x1[2][2];
+  auto read_w = [&](const char* half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) wf[i][ks] = lds_read8<T>(half + wrow + i * 16 * ROWB + foff[ks]);
+  };
+  auto read_x = [&](V8 (&x)[2][2], const char* half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) x[j][ks] = lds_read8<T>(half + xrow + j * 16 * ROWB + foff[ks]);
+  };
+  auto mma = [&](int i0, int j0, V8 (&x)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = mfma16<T>(wf[i][ks], x[j][ks], acc[i0 + i][j0 + j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define P8_BAR()                         \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");       \
+  } while (0)
+
+  // prologue: all of tile 0 (E) and X0 / W0 / X1 of tile 1 (O); W1(O) follows in phase 1
+  stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
+  stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  P8_BAR();
+  if (wr == 1) P8_BAR();   // the stagger
+
+  const int npair = nk >> 1;
+  for (int it = 0; it < npair; ++it) {
+    const int kt = 2 * it;
+    const bool more = it + 1 < npair;        // another pair follows: its half-tiles are staged in phases 2-8
+    char* E = smem;
+    char* O = smem + BUF;
+    // ---- phase 1 ----
+    read_x(x0, E + 2 * HALF);
+    __builtin_amdgcn_sched_barrier(0);
+    read_w(E);
+    stage(1, 1, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the X0 reads (issued first) are done: X0(E) may be restaged next phase
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(0, 0, x0);
+    P8_BAR();
+    // ---- phase 2 ----
+    read_x(x1, E + 3 * HALF);
+    if (more) stage(0, 2, kt + 2);
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(0, 2, x1);
+    P8_BAR();
+    // ---- phase 3 ----
+    read_w(E + HALF);
+    if (more) stage(0, 0, kt + 2);
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(4, 2, x1);
+    P8_BAR();
+    // ---- phase 4 ----
+    if (more) {
+      stage(0, 3, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    P8_BAR();
+    mma(4, 0, x0);
+    P8_BAR();
+    // ---- phase 5 ----
+    read_x(x0, O + 2 * HALF);
+    __builtin_amdgcn_sched_barrier(0);
+    read_w(O);
+    if (more) stage(0, 1, kt + 2);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(0, 0, x0);
+    P8_BAR();
+    // ---- phase 6 ----
+    read_x(x1, O + 3 * HALF);
+    if (more) stage(1, 2, kt + 3);
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(0, 2, x1);
+    P8_BAR();
+    // ---- phase 7 ----
+    read_w(O + HALF);
+    if (more) stage(1, 0, kt + 3);
+    P8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(4, 2, x1);
+    P8_BAR();
+    // ---- phase 8 ----
+    if (more) {
+      stage(1, 3, kt + 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    P8_BAR();
+    mma(4, 0, x0);
+    P8_BAR();
+  }
+  if (wr == 0) P8_BAR();   // re-join the two wave groups
+#undef P8_BAR
+  const int wn0 = wr * WTN, wm0 = wc * WTM;
+  if constexpr (STAGED) {
+    __syncthreads();
+    epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+  } else {
+    epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
+  }
+}
+
+// =================================================================================================
 // k128: two 128-deep buffers (256-byte rows) for the small projections (M <= 2048 rows)
 // =================================================================================================
 // The 64x64 / 128x128 launches of the 12-layer chain are latency-bound per K step (wait -> barrier ->
@@ -749,6 +943,21 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
   MRA_EPI_SWITCH((launch_k(gemm_ws_kernel<T, E>, a, 768, lds, stream)))
 }
 
+int g_p8 = 1;   // the eight-phase kernel for the 256 x 256 tile when K / 64 is even (0: the loader-wave kernel, for A/B runs and odd step counts)
+template <typename T>
+int launch_p8(const GemmArgs& a, int epi, hipStream_t stream) {
+  constexpr size_t lds = 2 * (256 + 256) * 128;
+  switch (epi) {
+    case EPI_OP: return launch_k(gemm_p8_kernel<T, EPI_OP>, a, 512, lds, stream);
+    case EPI_GELU_OP: return launch_k(gemm_p8_kernel<T, EPI_GELU_OP>, a, 512, lds, stream);
+    case EPI_KV: return launch_k(gemm_p8_kernel<T, EPI_KV>, a, 512, lds, stream);
+    case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP>, a, 512, lds, stream);
+    case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32>, a, 512, lds, stream);
+    case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32>, a, 512, lds, stream);
+    default: return -100;
+  }
+}
+
 template <typename T>
 int launch_ws_fold(const GemmArgs& a, int epi, hipStream_t stream) {   // 128 (weight rows) x 384 (activation rows)
   constexpr size_t lds = 2 * (128 + 384) * 128;
@@ -799,7 +1008,15 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
   }
 #endif
   if (g_variant != 1) {
-    if (cfg == 2) return launch_ws<T>(a, epi, stream);
+    if (cfg == 2) {
+      bool even = true;
+      for (int g = 0; g < a.ngroups; ++g) even = even && (a.p[g].K / 64) % 2 == 0 && a.p[g].K >= 128;
+      if (g_p8 && even) {
+        const int rc = launch_p8<T>(a, epi, stream);
+        if (rc != -100) return rc;
+      }
+      return launch_ws<T>(a, epi, stream);
+    }
     if (cfg == 0) {
       // 128-deep steps pay on the 64x64 tile once the K loop is long (FFN down-projection, K = 3072:
       // 367 -> 460 TF/s); at K = 768 the launch is prologue/epilogue-bound and nothing changes
@@ -824,6 +1041,7 @@ void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 void gemm_force_variant(int v) { g_variant = v; }
 static int g_order = 0;
 void gemm_set_tile_order(int order) { g_order = order; }
+void gemm_set_eight_phase(int on) { g_p8 = on; }
 void gemm_set_debug_buffer(unsigned long long* p) { g_dbg = p; }
 
 int gemm_pick_config(const GemmProb* probs, int ngroups) {

@@ -96,6 +96,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
 int gemm_pick_config(const GemmProb* probs, int ngroups);
 void gemm_force_config(int cfg);  // -1 = automatic (default)
 void gemm_set_debug_buffer(unsigned long long* dev_buf);  // variant 4 (stamped v1) writes 4 u64 per wave
+void gemm_set_eight_phase(int on);         // 256 x 256 launches with an even number of K steps on gemm_p8_kernel (A/B switch)
 void gemm_set_tile_order(int order);      // overrides GemmProb::order for every later launch when != 0 (A/B runs)
 void gemm_force_variant(int v);   // 5 = default (warp-specialised 256x256, two-buffer small tiles); 0 ring, 1 two-buffer,
                                   // 2 +L2 prefetch, 3 +spread DMA issue, 4 stamped diagnostic -- kept for A/B runs

@@ -120,7 +120,7 @@ static void order_ab(int rounds) {
   CK(hipMalloc((void**)&bias, 16384 * 4)); CK(hipMemset(bias, 0, 16384 * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int orders[] = {0x10000, 2, 4, 8, 16};   // 0x10000: the default walk (rows fastest in panels of 8 row tiles)
+  const int orders[] = {0x10000, 0x20000, 0x10000, 0x20000, 0x20008};   // 0x20000: the eight-phase kernel   // 0x10000: the default walk (rows fastest in panels of 8 row tiles)
   for (auto& s : shapes) {
     GemmProb p{};
     p.A = A; p.a = RowView{0, s.M, s.K}; p.W = W; p.bias = bias; p.C = C; p.c = RowView{0, s.M, s.N};
@@ -128,7 +128,8 @@ static void order_ab(int rounds) {
     if (s.epi == EPI_KV) { p.kv_tokens = s.M / 32; p.kv_items = 32; p.kv_heads = 12; }
     printf("%-30s", s.name);
     for (int o : orders) {
-      gemm_set_tile_order(o);
+      gemm_set_tile_order(o & 0x1ffff ? (o & 0x1ffff) : 0x10000);
+      gemm_set_eight_phase(o & 0x20000 ? 1 : 0);
       double best = 1e30;
       for (int r = 0; r < rounds; ++r) {
         if (launch_gemm(&p, 1, s.epi, OP_F16, 0)) { printf("launch failed\n"); return; }
@@ -140,12 +141,13 @@ static void order_ab(int rounds) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, (double)ms / 3);
       }
-      printf("  gn%-2d %5.0f", o & 0xff, 2.0 * s.M * s.N * s.K / best / 1e9);
+      printf("  %s gn%-2d %5.0f", o & 0x20000 ? "p8" : "ws", o & 0xff, 2.0 * s.M * s.N * s.K / best / 1e9);
     }
     printf("  TF/s\n");
     fflush(stdout);
   }
   gemm_set_tile_order(0);
+  gemm_set_eight_phase(0);
 }
 
 // would split-K pay on the layer chain's residual GEMMs?  One problem over the whole K against two problems over half of it each

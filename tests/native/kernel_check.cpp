@@ -1039,6 +1039,18 @@ int main(int argc, char** argv) {
     test_gemm(cfg, EPI_OP, OP_BF16, t + 3, t, 128, true);
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
+  // the eight-phase 256 x 256 kernel (even K / 64): every epilogue, ragged M, row views, two problems, K = 128 (one pair) .. 1408
+  gemm_set_eight_phase(1);
+  test_gemm(2, EPI_OP, OP_F16, 2 * 256 + 37, 512, 128, true);
+  test_gemm(2, EPI_KV, OP_F16, 2100, 1536, 1408, false);
+  test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
+  test_gemm(2, EPI_RES_F32, OP_F16, 2 * 256 + 37, 512, 384, true, 2);
+  test_gemm(2, EPI_F32, OP_BF16, 300, 512, 256, false);
+  test_gemm(2, EPI_RES_OP, OP_F16, 600, 512, 640, true);
+  test_gemm(2, EPI_OP, OP_BF16, 1000, 768, 768, false, 2);
+  test_gemm_masked(2, EPI_RES_F32, OP_F16, 700, 352, 128);
+  test_gemm_masked(2, EPI_F32, OP_F16, 300, 1408, 256);
+  gemm_set_eight_phase(0);
   test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1408, false);   // 256 x 256 tile with the GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
   gemm_set_tile_order(8);   // column-fastest panels (the ViT's N = 1408 GEMMs)

@@ -337,7 +337,7 @@ def test_folded_cross_attention_matches_kv_cache_path_and_oracle(video, audio, d
         qf.set_cross_mode("fold_rescale_pass")   # the split softmax with its rescale pass over P instead of the factors inside P.enc
         resc = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
         qf.set_cross_mode("auto")
-        assert (resc["query"] - got["query"]).abs().max().item() < 2e-3 and (resc["cls"] - got["cls"]).abs().max().item() < 2e-3
+        assert (resc["query"] - ref["query"]).abs().max().item() < 5e-3 and (resc["cls"] - ref["cls"]).abs().max().item() < 5e-3
         assert (strm["query"] - ref["query"]).abs().max().item() < 5e-3 and (strm["cls"] - ref["cls"]).abs().max().item() < 5e-3
         assert (got["query"] - ref["query"]).abs().max().item() < 5e-3, (kv, (got["query"] - ref["query"]).abs().max().item())
         assert (got["cls"] - ref["cls"]).abs().max().item() < 5e-3
