@@ -94,8 +94,104 @@ __device__ __forceinline__ GemmProb tile_of(const GemmArgs& args, int id, int& n
 
 // lane owns C[m][n .. n+3]: m = column (lane & 15) of tile j, n = 4 * (lane >> 4) + reg of tile i
 // PRE: bias and residual are already inside the accumulators (accumulators_from_residual below)
+// Every read (bias, residual, the GELU backward's pre-activation) is issued up front from clamped, always valid addresses and
+// none sits under a branch: a conditional around a fragment's load makes the compiler close each fragment with vmcnt(0), i.e.
+// one memory round trip per fragment in series (4-16 of them per wave on the layer chain's tiles).
 template <typename T, int FN, int FM, int EPI, bool PRE = false>
 __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM], int n_base, int m_base, int lane) {
+  const int lm = lane & 15, ln = (lane >> 4) * 4;
+  const int M = P.M;
+  constexpr bool RES = EPI == EPI_RES_F32 && !PRE;
+  int nc[FN];
+  bool cok[FN];
+  f32x4 bv[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n_base + i * 16 + ln;
+    cok[i] = !P.n_mask || n < P.N;
+    nc[i] = cok[i] ? n : 0;
+    bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!PRE && P.bias) bv[i] = *reinterpret_cast<const f32x4*>(P.bias + nc[i]);
+  }
+  long long coff[FM], roff[FM];
+  bool rok[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m_base + j * 16 + lm;
+    rok[j] = m < M;
+    const int mc = min(m, M - 1);
+    coff[j] = EPI == EPI_KV ? 0 : view_off(P.c, mc);
+    roff[j] = RES ? view_off(P.r, mc) : 0;
+  }
+  f32x4 rv[RES ? FN : 1][RES ? FM : 1];
+  typename Vec4<T>::type uv[EPI == EPI_GELU_BWD ? FN : 1][EPI == EPI_GELU_BWD ? FM : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) rv[i][j] = *reinterpret_cast<const f32x4*>(P.R + roff[j] + nc[i]);
+  }
+  if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) uv[i][j] = *reinterpret_cast<const typename Vec4<T>::type*>((const T*)P.aux + coff[j] + nc[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    int item = 0, tok = 0;
+    if constexpr (EPI == EPI_KV) {
+      const int m = min(m_base + j * 16 + lm, M - 1);
+      item = m / P.kv_tokens;
+      tok = m - item * P.kv_tokens;
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = nc[i];
+      const bool live = rok[j] && cok[i];
+      f32x4 v = acc[i][j] + bv[i];
+      if constexpr (EPI == EPI_GELU_OP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if constexpr (EPI == EPI_GELU_BOTH) {     // keep the pre-activation for the backward, return the activation
+        typename Vec4<T>::type u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = from_f32<T>(v[e]); v[e] = gelu_erf((float)u[e]); }
+        if (live) *reinterpret_cast<typename Vec4<T>::type*>((T*)P.aux + coff[j] + n) = u;
+      }
+      if constexpr (EPI == EPI_GELU_BWD) {      // d(pre-activation) = d(activation) * gelu'(pre-activation)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad((float)uv[i][j][e]);
+      }
+      if constexpr (RES) v += rv[i][j];
+      if (!live) continue;
+      if constexpr (EPI == EPI_RES_F32 || EPI == EPI_F32) {
+        *reinterpret_cast<f32x4*>((float*)P.C + coff[j] + n) = v;
+      } else {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+        if constexpr (EPI == EPI_KV) {
+          const int hidden = P.kv_heads * 64;
+          const int sel = n / hidden;           // cl * 2 + kv
+          const int within = n - sel * hidden;  // head * 64 + d
+          const int head = within >> 6, d = within & 63;
+          const long long dst =
+              ((((long long)sel * P.kv_items + item) * P.kv_heads + head) * P.kv_tokens + tok) * 64 + d;
+          *reinterpret_cast<typename Vec4<T>::type*>((T*)P.C + dst) = o;
+        } else {
+          *reinterpret_cast<typename Vec4<T>::type*>((T*)P.C + coff[j] + n) = o;
+        }
+      }
+    }
+  }
+}
+
+// The same epilogue with every read next to its use: for the loader-wave kernels, which sit at the 168-register cap of three waves per
+// SIMD and have no room for the up-front loads (their 176 x 384 / 256 x 256 direct epilogues spilled 100-400 bytes per lane with them).
+template <typename T, int FN, int FM, int EPI, bool PRE = false>
+__device__ __forceinline__ void epilogue_lean(const GemmProb& P, f32x4 (&acc)[FN][FM], int n_base, int m_base, int lane) {
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   const int M = P.M;
 #pragma unroll
@@ -417,7 +513,8 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
-    epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
+    if constexpr (FN * FM > 16) epilogue_lean<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);   // 256 x 256 on 8 waves (A/B variant only): no room for the up-front loads
+    else epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
 }
 
@@ -618,7 +715,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
-    epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
+    epilogue_lean<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
 }
 
