@@ -394,11 +394,22 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
   for (int u = 0; u < RPB; ++u) {
     const int row = (tid >> 3) + u * (NT / 8);
     live[u] = m0 + row < P.M;
-    int item = item0, r = r0 + row;
+    int item = item0, r = r0 + (live[u] ? row : P.M - 1 - m0);   // dead rows: the address of the last live one (read, never stored)
     while (r >= rpi) { r -= rpi; ++item; }
     const int cc = c ^ (row & 7);
     if constexpr (EPI == EPI_KV) rowoff[u] = ((long long)item * P.kv_heads * P.kv_tokens + r) * 64 + cc * 8;
     else rowoff[u] = (long long)item * P.c.item_stride + (long long)r * P.c.ld + cc * 8;
+  }
+  // EPI_RES_OP: all residual chunks first (masked column blocks read block 0 of the tile), none under a branch -- a load per
+  // (block, row) next to its add is one serial memory round trip each, 16 per thread on the 256 x 256 tile
+  typename Vec8<T>::type resid[EPI == EPI_RES_OP ? TN / 64 : 1][EPI == EPI_RES_OP ? RPB : 1];
+  if constexpr (EPI == EPI_RES_OP) {
+#pragma unroll
+    for (int hq = 0; hq < TN / 64; ++hq) {
+      const int nb = n0 + hq * 64 < P.N ? n0 + hq * 64 : n0;
+#pragma unroll
+      for (int u = 0; u < RPB; ++u) resid[hq][u] = *reinterpret_cast<const typename Vec8<T>::type*>((const T*)P.aux + nb + rowoff[u]);
+    }
   }
 #pragma unroll
   for (int hq = 0; hq < TN / 64; ++hq) {
@@ -418,9 +429,8 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
       const int q = tid + (hq * RPB + u) * NT;
       typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
       if constexpr (EPI == EPI_RES_OP) {   // + the residual in the operand dtype, whole 16-byte chunks (the reference's fp16 add)
-        const typename Vec8<T>::type r = *reinterpret_cast<const typename Vec8<T>::type*>((const T*)P.aux + blk + rowoff[u]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] = from_f32<T>((float)val[e] + (float)r[e]);
+        for (int e = 0; e < 8; ++e) val[e] = from_f32<T>((float)val[e] + (float)resid[hq][u][e]);
       }
       *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + blk + rowoff[u]) = val;
     }
