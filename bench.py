@@ -196,7 +196,7 @@ def main():
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
     # PMC passes of the build in force: the in-register rescale (default) or the separate rescale pass (cross mode 5 = the r02 mid-round build)
-    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r02b_pmc_fold.json")
+    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r02c_pmc_fold.json")
     if not os.path.exists(fold_pmc):
         fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
     traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
