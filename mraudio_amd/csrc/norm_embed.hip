@@ -41,13 +41,18 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* x, RowView xv
   if (gain2 && row % period >= split) { gain = gain2; bias = bias2; }
   constexpr int H = NV * 256;
   const float* xr = x + vrow(xv, row);
-  f32x4 v[NV];
-  float s = 0.f;
+  f32x4 v[NV], g[NV], b[NV];
+  // gain and bias ride the same round trip as the row (read next to their use, behind the o32 / o16 branches, each of the NV
+  // pieces cost its own)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
-    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    g[i] = *reinterpret_cast<const f32x4*>(gain + (i * 64 + lane) * 4);
+    b[i] = *reinterpret_cast<const f32x4*>(bias + (i * 64 + lane) * 4);
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float mean = wave_sum(s) * (1.0f / H);
   float q = 0.f;
 #pragma unroll
@@ -61,11 +66,9 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const float* x, RowView xv
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
     f32x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rstd * g[e] + b[e];
+    for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rstd * g[i][e] + b[i][e];
     if (o32) *reinterpret_cast<f32x4*>(o32 + c) = y;
     if (o16) store4<T>(o16 + c, y);
   }
