@@ -351,16 +351,32 @@ __device__ __forceinline__ void epilogue_softpart(const GemmProb& P, f32x4 (&acc
 // 16-byte chunks out in LDS order: one wave instruction = 8 rows x 128 B, whole lines; for the
 // head-major K/V cache that is 1 KiB contiguous.  Must be entered after a workgroup barrier (the K
 // loop's LDS reads are over); smem needs TN * TM * 2 bytes.
-template <typename T, int TN, int TM, int FN, int FM, int NT, int EPI>
+// BIAS_FIRST: all FN bias pieces in one round trip before the staging loop (a load per fragment next to its use is one round trip
+// per fragment); only on the small tiles: with 128 accumulators live the extra 4 FN registers spill (650-800 bytes per lane at the loader-wave
+// kernels' 168-register budget, 300-350 in the eight-phase kernel).
+template <typename T, int TN, int TM, int FN, int FM, int NT, int EPI, bool BIAS_FIRST = false>
 __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[FN][FM], char* smem, int n0, int m0, int wn0,
                                                int wm0, int tid) {
   const int lane = tid & 63;
   const int lm = lane & 15, ln = (lane >> 4) * 4;
+  f32x4 bias4[BIAS_FIRST ? FN : 1];
+  if constexpr (BIAS_FIRST) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn0 + i * 16 + ln;
+      bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (P.bias) {
+        bias4[i] = *reinterpret_cast<const f32x4*>(P.bias + (n < P.N ? n : 0));
+        if (n >= P.N) bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int nl = wn0 + i * 16 + ln;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+    if constexpr (BIAS_FIRST) bv = bias4[i];
+    else if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
     const int hq = nl >> 6, d = nl & 63;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -521,7 +537,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_kernel(const GemmArgs args
   }
   if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) {
     __syncthreads();
-    epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+    epilogue_lds16<T, TN, TM, FN, FM, NT, EPI, (FN * FM <= 16)>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
     if constexpr (FN * FM > 16) epilogue_lean<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);   // 256 x 256 on 8 waves (A/B variant only): no room for the up-front loads
     else epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
@@ -1007,7 +1023,7 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_k128_kernel(const GemmArgs
   }
   if constexpr (EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP) {
     __syncthreads();
-    epilogue_lds16<T, TN, TM, FN, FM, NT, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+    epilogue_lds16<T, TN, TM, FN, FM, NT, EPI, (FN * FM <= 16)>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
     epilogue<T, FN, FM, EPI>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
