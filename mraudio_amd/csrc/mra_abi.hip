@@ -529,7 +529,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         d.A = w.qc16; d.a = qc_rows; d.a_bs = 64;
         d.W = h->arena_f + (size_t)ci * H * E * esz; d.w_bs = (long long)E * 64;
         d.C = w.qp16; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * esz;
-        d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = 1;
+        d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
         rc = launch_gemm(&d, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold q' gemm");
         if (stream_fold) {
@@ -596,7 +596,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         cx.W = (const char*)h->wkv + (size_t)(ci * 2 + 1) * H * E * esz; cx.w_bs = (long long)64 * E;
         cx.bias = h->bkv + (size_t)(ci * 2 + 1) * H; cx.bias_bs = 64;
         cx.C = w.ctx16; cx.c = qc_rows; cx.c_bs_bytes = 64 * esz;
-        cx.M = N * Q; cx.N = 64; cx.K = E; cx.batch = c.heads; cx.tile_cfg = 1;
+        cx.M = N * Q; cx.N = 64; cx.K = E; cx.batch = c.heads; cx.tile_cfg = E % 128 == 0 && N * Q >= 512 ? 6 : 1;
         rc = launch_gemm(&cx, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold context gemm");
         if (timed) (void)hipEventRecord(h->kv_ev1, stream);
