@@ -8,8 +8,11 @@
 // output row m.  gfx950, v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulation.
 //
 // Main loops (one per regime):
-//   gemm_ws_kernel    256x256x64, the K/V projection and every launch with >= 512 tiles: 8 compute
-//                     waves + 4 LDS-DMA loader waves per workgroup.
+//   gemm_p8_kernel    256x256x64 in eight phases per pair of K tiles (8 waves, SIMD partners one barrier apart, half-tile DMA
+//                     staging with counted vmcnt): the K/V projection, the ViT's four GEMMs, every launch with >= 512 tiles
+//                     and an even number of K steps.
+//   gemm_ws_kernel    8 compute waves + 4 LDS-DMA loader waves per workgroup: the 176x384 / 128x384 tiles of the folded
+//                     cross-attention, and 256x256 with an odd number of K steps.
 //   gemm_kernel       64x64 / 128x128 tiles of the 12-layer chain: two 64-deep LDS buffers.
 //   gemm_k128_kernel  the same with 128-deep steps, for the long-K down-projections.
 // Operands are staged by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction); the
