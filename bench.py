@@ -254,11 +254,11 @@ def main():
                           "algorithmic_flops_per_launch": block_alg, "algorithmic_tflops": round(block_alg / (kv_step_ms * 1e-3) / 1e12, 1),
                           "hbm": None if not traffic else {"achieved": round(traffic / (kv_step_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                                           "frac": round(traffic / (kv_step_ms * 1e-3) / 1e9 / 8000.0, 4)},
-                          "kv_cache_mode_gemm": {"kernel": "gemm_ws_kernel<256x256x64, EPI_KV> (what --cross-mode kv_cache runs instead)",
+                          "kv_cache_mode_gemm": {"kernel": "gemm_p8_kernel<EPI_KV> (eight-phase 256x256x64; what --cross-mode kv_cache runs instead)",
                                                  "standalone_launch_ms": round(kv_ms, 4),
                                                  "standalone_tflops": round(kv_flops / (kv_ms * 1e-3) / 1e12, 1)}}
                          if folded else
-                         {"bound": "mfma", "kernel": "gemm_ws_kernel<256x256x64, EPI_KV> (K/V projection of all cross layers, video)",
+                         {"bound": "mfma", "kernel": "gemm_p8_kernel<EPI_KV> (eight-phase 256x256x64; K/V projection of all cross layers, video)",
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                           "traffic_source": traffic_src,
