@@ -189,7 +189,7 @@ def main():
     del cache, enc
 
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_kvproj_ws.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02c_pmc_kvproj_p8.json")   # the eight-phase kernel; r01_pmc_kvproj_ws.json holds the loader-wave kernel's
     if not folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(pmc_file):
         # HBM-side bytes per launch from a separate rocprofv3 --pmc pass of the same kernel and shape
         # (PMC cannot be collected from inside this process); see the file's _note for the gfx950 correction
@@ -199,7 +199,7 @@ def main():
     fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r02c_pmc_fold.json")
     if not os.path.exists(fold_pmc):
         fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
-    traffic_src = "profiles/r01_pmc_kvproj_ws.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
+    traffic_src = "profiles/r02c_pmc_kvproj_p8.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
     if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
         traffic_src = f"profiles/{os.path.basename(fold_pmc)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
