@@ -766,39 +766,56 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
 // Reads of a retired buffer start one phase after the wait (every wave's wait + a barrier in between); a slot is restaged two
 // phases after its last read (X0: one phase after, its reads are retired by lgkmcnt(8) before phase 1's first barrier).
 // K / 64 must be even and >= 2.  Epilogues: those of the loader-wave kernel.
-template <typename T, int EPI>
-__global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
-  constexpr int TN = 256, TM = 256, BK = 64, ROWB = BK * 2, WGM = 4, WTN = 128, WTM = 64, FN = 8, FM = 4;
-  constexpr int HALF = 128 * ROWB, BUF = 4 * HALF;   // 16 KB half-tiles: W0, W1, X0, X1; 64 KB per K tile
+// TAIL: the same schedule on a 128 (weight rows) x 512 (activation rows) tile, for the half-width last column tile of N = 256 k + 128
+// (the ViT's N = 1408 GEMMs): both wave groups share the 128 weight rows and take 256 activation rows each, so W0 / W1 are 8 KB (one DMA
+// instruction per wave) and X0 / X1 32 KB (four): 80 KB per K tile, all 160 KB of LDS, vmcnt(9) = 4 + 1 + 4 for the three youngest
+// half-tiles.  Reads, MFMAs and barriers are unchanged.
+template <typename T, int EPI, bool TAIL>
+__device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) {
+  constexpr int TN = TAIL ? 128 : 256, TM = TAIL ? 512 : 256, BK = 64, ROWB = BK * 2, WTN = 128, WTM = 64, FN = 8, FM = 4;
+  constexpr int WHALF = (TAIL ? 64 : 128) * ROWB, XHALF = (TAIL ? 256 : 128) * ROWB;   // half-tile sizes: W0, W1 | X0, X1
+  constexpr int BUF = 2 * WHALF + 2 * XHALF;                                           // 64 KB (80 KB) per K tile
+  constexpr int WP = WHALF / 8192, XP = XHALF / 8192;                                  // DMA instructions per wave and half-tile
   constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  int n0, m0;
-  const GemmProb& P = pick_tile<TN, TM>(args, n0, m0);
   const int K = P.K, M = P.M;
   const int nk = K / BK;
 
-  // DMA sources: half h, piece c (this lane's chunk q = tid + 512 c of the half's 1024): LDS row q >> 3, physical chunk q & 7
-  const char* src[4][2];
+  // DMA sources: piece c of a half-tile is this lane's chunk q = tid + 512 c: LDS row q >> 3, physical chunk q & 7
+  const char* srcw[2][WP];
+  const char* srcx[2][XP];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < WP; ++c) {
     const int q = tid + c * 512;
     const int r = q >> 3, ch = (q & 7) ^ ((r >> 1) & 7);
-    const int w0row = (r < 64 ? r : 64 + r), w1row = w0row + 64;                 // rows 0-63 | 128-191, then 64-127 | 192-255
-    const int x0row = (r >> 5) * 64 + (r & 31), x1row = x0row + 32;              // 32 of every wc's 64
-    src[0][c] = (const char*)P.W + ((long long)min(n0 + w0row, P.N - 1) * K + ch * 8) * 2;
-    src[1][c] = (const char*)P.W + ((long long)min(n0 + w1row, P.N - 1) * K + ch * 8) * 2;
-    src[2][c] = (const char*)P.A + (view_off(P.a, min(m0 + x0row, M - 1)) + ch * 8) * 2;
-    src[3][c] = (const char*)P.A + (view_off(P.a, min(m0 + x1row, M - 1)) + ch * 8) * 2;
+    // 256-row tile: rows 0-63 | 128-191 (W0), 64-127 | 192-255 (W1); tail: rows 0-63 (W0), 64-127 (W1)
+    const int w0row = TAIL ? r : (r < 64 ? r : 64 + r);
+    srcw[0][c] = (const char*)P.W + ((long long)min(n0 + w0row, P.N - 1) * K + ch * 8) * 2;
+    srcw[1][c] = (const char*)P.W + ((long long)min(n0 + w0row + 64, P.N - 1) * K + ch * 8) * 2;
   }
-  auto stage = [&](int buf, int h, int kt) {
-    char* base = smem + buf * BUF + h * HALF + wave * 1024;
+#pragma unroll
+  for (int c = 0; c < XP; ++c) {
+    const int q = tid + c * 512;
+    const int r = q >> 3, ch = (q & 7) ^ ((r >> 1) & 7);
+    const int x0row = (r >> 5) * 64 + (r & 31);              // 32 of every wave's 64 rows (wave index r >> 5: wc, or 4 wr + wc in the tail)
+    srcx[0][c] = (const char*)P.A + (view_off(P.a, min(m0 + x0row, M - 1)) + ch * 8) * 2;
+    srcx[1][c] = (const char*)P.A + (view_off(P.a, min(m0 + x0row + 32, M - 1)) + ch * 8) * 2;
+  }
+  auto stage = [&](int buf, int h, int kt) {   // h: 0 W0, 1 W1, 2 X0, 3 X1
     const long long koff = (long long)kt * ROWB;
-    glds16(src[h][0] + koff, base);
-    glds16(src[h][1] + koff, base + 8192);
+    if (h < 2) {
+      char* base = smem + buf * BUF + h * WHALF + wave * 1024;
+#pragma unroll
+      for (int c = 0; c < WP; ++c) glds16(srcw[h][c] + koff, base + c * 8192);
+    } else {
+      char* base = smem + buf * BUF + 2 * WHALF + (h - 2) * XHALF + wave * 1024;
+#pragma unroll
+      for (int c = 0; c < XP; ++c) glds16(srcx[h - 2][c] + koff, base + c * 8192);
+    }
   };
   int foff[2];
 #pragma unroll
@@ -807,13 +824,13 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     const int c = (4 * ks + (lane >> 4)) ^ ((r >> 1) & 7);
     foff[ks] = r * ROWB + c * 16;
   }
-  const int wrow = wr * 64 * ROWB, xrow = wc * 32 * ROWB;   // this wave's rows inside a W / X half-tile
+  const int wrow = TAIL ? 0 : wr * 64 * ROWB, xrow = (TAIL ? wave : wc) * 32 * ROWB;   // this wave's rows inside a W / X half-tile
 
   f32x4 acc[FN][FM];
   if constexpr (EPI == EPI_RES_F32) {
     // issued BEFORE the prologue's DMA: older in the vmcnt order, so the prologue's vmcnt(6) covers them and their latency
     // overlaps the first half-tiles' (an ordinary load still pending inside the loop would make the compiler drain everything)
-    accumulators_from_residual<FN, FM>(P, acc, n0 + wr * WTN, m0 + wc * WTM, lane);
+    accumulators_from_residual<FN, FM>(P, acc, n0 + (TAIL ? 0 : wr * WTN), m0 + (TAIL ? wave : wc) * WTM, lane);
   } else {
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -855,7 +872,7 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
   // prologue: all of tile 0 (E) and X0 / W0 / X1 of tile 1 (O); W1(O) follows in phase 1
   stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
   stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   P8_BAR();
   if (wr == 1) P8_BAR();   // the stagger
 
@@ -866,7 +883,7 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     char* E = smem;
     char* O = smem + BUF;
     // ---- phase 1 ----
-    read_x(x0, E + 2 * HALF);
+    read_x(x0, E + 2 * WHALF);
     __builtin_amdgcn_sched_barrier(0);
     read_w(E);
     stage(1, 1, kt + 1);
@@ -876,14 +893,14 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     mma(0, 0, x0);
     P8_BAR();
     // ---- phase 2 ----
-    read_x(x1, E + 3 * HALF);
+    read_x(x1, E + 2 * WHALF + XHALF);
     if (more) stage(0, 2, kt + 2);
     P8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mma(0, 2, x1);
     P8_BAR();
     // ---- phase 3 ----
-    read_w(E + HALF);
+    read_w(E + WHALF);
     if (more) stage(0, 0, kt + 2);
     P8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -892,7 +909,7 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     // ---- phase 4 ----
     if (more) {
       stage(0, 3, kt + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -900,7 +917,7 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     mma(4, 0, x0);
     P8_BAR();
     // ---- phase 5 ----
-    read_x(x0, O + 2 * HALF);
+    read_x(x0, O + 2 * WHALF);
     __builtin_amdgcn_sched_barrier(0);
     read_w(O);
     if (more) stage(0, 1, kt + 2);
@@ -910,14 +927,14 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     mma(0, 0, x0);
     P8_BAR();
     // ---- phase 6 ----
-    read_x(x1, O + 3 * HALF);
+    read_x(x1, O + 2 * WHALF + XHALF);
     if (more) stage(1, 2, kt + 3);
     P8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mma(0, 2, x1);
     P8_BAR();
     // ---- phase 7 ----
-    read_w(O + HALF);
+    read_w(O + WHALF);
     if (more) stage(1, 0, kt + 3);
     P8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -926,7 +943,7 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
     // ---- phase 8 ----
     if (more) {
       stage(1, 3, kt + 3);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
     P8_BAR();
     mma(4, 0, x0);
@@ -934,12 +951,43 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
   }
   if (wr == 0) P8_BAR();   // re-join the two wave groups
 #undef P8_BAR
-  const int wn0 = wr * WTN, wm0 = wc * WTM;
+  const int wn0 = TAIL ? 0 : wr * WTN, wm0 = (TAIL ? wave : wc) * WTM;
   if constexpr (STAGED) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
     epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
+  }
+}
+
+template <typename T, int EPI, bool TAIL = false>
+__global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
+  int n0, m0;
+  const GemmProb P = pick_tile<(TAIL ? 128 : 256), (TAIL ? 512 : 256)>(args, n0, m0);
+  gemm_p8_tile<T, EPI, TAIL>(P, n0, m0);
+}
+
+// N = 256 k + 128 (the ViT's N = 1408) without a masked half tile AND without a second pass over the activations: one launch, eleven
+// workgroups per pair of 256-row tiles -- 2 x k full 256 x 256 tiles, then the pair's last 128 columns as one 128 x 512 tile -- in
+// that order after the XCD remap, so the tiles that share activation rows run together and share them in L2.  (As its own launch
+// the tail re-streams every activation row from HBM: measured slower than the masked tile.)  One problem, no batch.
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) gemm_p8_mixed_kernel(const GemmArgs args) {
+  int id = blockIdx.x;
+  {
+    const int nwg = args.total_tiles;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const GemmProb& P = args.p[0];
+  const int kfull = P.N >> 8, per = 2 * kfull + 1;     // full column tiles per row tile; workgroups per pair of row tiles
+  const int pair = id / per, w = id - pair * per;
+  if (w == 2 * kfull) {
+    gemm_p8_tile<T, EPI, true>(P, kfull * 256, pair * 512);
+  } else {
+    const int rt = 2 * pair + w / kfull;
+    if (rt * 256 >= P.M) return;                         // odd number of row tiles: the last pair has one
+    gemm_p8_tile<T, EPI, false>(P, (w % kfull) * 256, rt * 256);
   }
 }
 
@@ -1085,8 +1133,17 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
 
 int g_p8 = 1;   // the eight-phase kernel for the 256 x 256 tile when K / 64 is even (0: the loader-wave kernel, for A/B runs and odd step counts)
 template <typename T>
-int launch_p8(const GemmArgs& a, int epi, hipStream_t stream) {
+int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false) {
   constexpr size_t lds = 2 * (256 + 256) * 128;
+  if (tail) {   // 128 x 512 tile: 2 x 80 KB
+    constexpr size_t ldst = 2 * (128 + 512) * 128;
+    switch (epi) {
+      case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP, true>, a, 512, ldst, stream);
+      case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32, true>, a, 512, ldst, stream);
+      case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32, true>, a, 512, ldst, stream);
+      default: return -2;
+    }
+  }
   switch (epi) {
     case EPI_OP: return launch_k(gemm_p8_kernel<T, EPI_OP>, a, 512, lds, stream);
     case EPI_GELU_OP: return launch_k(gemm_p8_kernel<T, EPI_GELU_OP>, a, 512, lds, stream);
@@ -1141,6 +1198,16 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
   if (cfg == 3) return launch_ws_fold<T>(a, epi, stream);
   if (cfg == 4) return launch_ws_pv<T>(a, epi, stream);
   if (cfg == 5) return launch_k128<T, 64, 128, 2, 2>(a, epi, stream);   // 64 weight rows x 128 activation rows, 128-deep steps
+  if (cfg == 6) return launch_p8<T>(a, epi, stream, true);              // 128 weight rows x 512 activation rows, eight phases
+  if (cfg == 7) {                                                        // N = 256 k + 128: full tiles + one 128 x 512 tail tile per pair of row tiles
+    constexpr size_t ldst = 2 * (128 + 512) * 128;
+    switch (epi) {
+      case EPI_RES_OP: return launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream);
+      case EPI_RES_F32: return launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream);
+      case EPI_F32: return launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream);
+      default: return -2;
+    }
+  }
 #ifdef MRA_GEMM_EXPERIMENTS
   if (g_variant != 5 && g_variant != 1) {
     const int rc = launch_experiment<T>(a, cfg, epi, g_variant, stream);
@@ -1171,8 +1238,8 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
 }
 
 constexpr int kTile[3] = {64, 128, 256};
-constexpr int kTileN[6] = {64, 128, 256, 128, 176, 64};   // weight rows per tile
-constexpr int kTileM[6] = {64, 128, 256, 384, 384, 128};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
+constexpr int kTileN[8] = {64, 128, 256, 128, 176, 64, 128, 256};   // weight rows per tile (config 7: 256, then 128 for the last column tile)
+constexpr int kTileM[8] = {64, 128, 256, 384, 384, 128, 512, 256};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
 
 }  // namespace
 
@@ -1211,7 +1278,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
   if (ngroups < 1 || ngroups > 2) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
-  if (cfg < 0 || cfg > 5) return -1;
+  if (cfg < 0 || cfg > 7) return -1;
   const int t = kTileN[cfg], tm = kTileM[cfg];
   GemmArgs a;
   a.ngroups = ngroups;
@@ -1220,8 +1287,10 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     a.p[g] = probs[g];
     GemmProb& p = a.p[g];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
-    if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask)) return -1;
+    if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask && cfg != 7)) return -1;
     if (cfg == 5 && p.K % 128) return -1;
+    if (cfg == 6 && (p.K % 128 || p.N != 128 || p.n_mask || p.n_ragged || p.batch > 1)) return -1;   // the eight-phase tail tile: one column tile, even K steps
+    if (cfg == 7 && (p.K % 128 || p.N % 256 != 128 || p.N < 384 || p.n_mask || p.n_ragged || p.batch > 1 || ngroups != 1)) return -1;
     if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32 && epi != EPI_RES_OP && epi != EPI_OP && epi != EPI_GELU_OP) || (p.N & 3) || p.n_ragged)) return -1;
     if (p.n_mask && epi != EPI_RES_F32 && epi != EPI_F32 && (p.N & 63)) return -1;   // the 16-bit epilogues leave in 64-column blocks
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
@@ -1238,7 +1307,8 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     p.mtiles = (p.M + tm - 1) / tm;
     p.ntiles = (p.N + t - 1) / t;
     p.tile_begin = tiles;
-    tiles += p.mtiles * p.ntiles * (p.batch > 1 ? p.batch : 1);
+    if (cfg == 7) tiles += (p.mtiles + 1) / 2 * (2 * (p.N >> 8) + 1);   // per pair of row tiles: 2 k full tiles + one tail tile
+    else tiles += p.mtiles * p.ntiles * (p.batch > 1 ? p.batch : 1);
   }
   if (ngroups == 1) a.p[1] = a.p[0];
   a.total_tiles = tiles;

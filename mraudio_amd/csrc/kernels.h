@@ -74,7 +74,10 @@ struct GemmProb {
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation
                    // rows) loader-wave tile (EPI_OP / EPI_F32 only), 5 = 176 x 384 with the compute waves in one column (EPI_OP only,
                    // N % 176 == 0), 6 = 64 (weight rows) x 128 (activation rows) with 128-deep K steps (K % 128 == 0: the long-K down-projections of
-                   // the layer chain at ~1 k rows, where a tile's bytes per flop, not its count, sets the time); the first problem decides
+                   // the layer chain at ~1 k rows, where a tile's bytes per flop, not its count, sets the time), 7 = 128 (weight rows) x 512
+                   // (activation rows) on the eight-phase kernel (N = 128 exactly: the half-width last column tile of N = 256 k + 128, launched on its
+                   // own with W / bias / C / R offset to those columns; EPI_RES_F32 / EPI_F32 / EPI_RES_OP, K % 128 == 0), 8 = N = 256 k + 128 in ONE launch:
+                   // full 256 x 256 eight-phase tiles plus one 128 x 512 tail tile per pair of row tiles (same epilogues, one problem); the first problem decides
   int order;       // tile walk: 0 = panels of 8 row tiles, rows fastest; gn > 0 = panels of gn column tiles walked down the rows, columns
                    // fastest (measured better for the ViT's N = 1408 GEMMs: all 6 column tiles of a row tile run together)
   int tile_begin;  // filled by the launcher

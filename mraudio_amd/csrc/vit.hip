@@ -266,6 +266,7 @@ struct mra_vit {
   float *cls = nullptr, *pos = nullptr, *bpatch = nullptr;
   void* wpatch = nullptr;
   std::vector<VitLayer> layers;
+  bool tail_tile = true;   // N = dim GEMMs: full 256-wide tiles + a 128 x 512 tail tile per pair of row tiles (false: a masked sixth 256-wide column tile)
   int proj_tile = 3;   // GemmProb::tile_cfg of the N = dim GEMMs: 256 x 256 with a masked last column tile (1408 = 5.5 tiles); the exact-fit
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
@@ -475,14 +476,20 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
       else hipLaunchKernelGGL((vit_attn_kernel<bf16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
     }
-    {
+    // x += A W^T + b for the two N = dim GEMMs.  dim = 1408 is 5.5 tiles of 256: GemmProb::tile_cfg 8 runs the five full column tiles
+    // of two row tiles and then their last 128 columns as one 128 x 512 tile, all in one launch (a masked sixth 256-wide tile wastes 9 %)
+    auto residual_gemm = [&](const void* A, int K, const void* W, const float* bias) {
       GemmProb p{};
-      p.A = a16; p.a = plain((int)M, D); p.W = L.wproj; p.bias = L.bproj;
+      p.A = A; p.a = plain((int)M, K); p.W = W; p.bias = bias;
       p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
-      p.M = (int)M; p.N = D; p.K = D; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
-      rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
-      if (rc) return chk(rc, "vit projection gemm");
-    }
+      p.M = (int)M; p.N = D; p.K = K; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
+      const int epi = r16 ? EPI_RES_OP : EPI_RES_F32;
+      const bool split = h->proj_tile == 3 && h->tail_tile && D % 256 == 128 && D > 128 && K % 128 == 0;
+      if (split) { p.tile_cfg = 8; p.n_mask = 0; p.order = 0; }
+      return launch_gemm(&p, 1, epi, op, st);
+    };
+    rc = residual_gemm(a16, D, L.wproj, L.bproj);
+    if (rc) return chk(rc, "vit projection gemm");
     rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
     if (rc) return chk(rc, "vit ln2");
     {
@@ -492,14 +499,8 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       rc = launch_gemm(&p, 1, EPI_GELU_OP, op, st);
       if (rc) return chk(rc, "vit fc1 gemm");
     }
-    {
-      GemmProb p{};
-      p.A = big; p.a = plain((int)M, I); p.W = L.wfc2; p.bias = L.bfc2;
-      p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
-      p.M = (int)M; p.N = D; p.K = I; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
-      rc = launch_gemm(&p, 1, r16 ? EPI_RES_OP : EPI_RES_F32, op, st);
-      if (rc) return chk(rc, "vit fc2 gemm");
-    }
+    rc = residual_gemm(big, I, L.wfc2, L.bfc2);
+    if (rc) return chk(rc, "vit fc2 gemm");
   }
   return hipGetLastError() == hipSuccess ? MRA_OK : fail(MRA_EHIP, "vit forward launch");
 }

@@ -1050,6 +1050,14 @@ int main(int argc, char** argv) {
   test_gemm(2, EPI_OP, OP_BF16, 1000, 768, 768, false, 2);
   test_gemm_masked(2, EPI_RES_F32, OP_F16, 700, 352, 128);
   test_gemm_masked(2, EPI_F32, OP_F16, 300, 1408, 256);
+  test_gemm(6, EPI_RES_F32, OP_F16, 1300, 128, 384, true);        // the 128 x 512 form (tile_cfg 7): one column tile, ragged M, views
+  test_gemm(6, EPI_F32, OP_BF16, 1000, 128, 128, false);
+  test_gemm(6, EPI_RES_OP, OP_F16, 700, 128, 1408, true);
+  test_gemm(6, EPI_RES_F32, OP_F16, 512, 128, 6144, false);
+  test_gemm(7, EPI_RES_F32, OP_F16, 1300, 384, 256, true);         // tile_cfg 8: 256-wide tiles + 128 x 512 tail tiles in one launch; odd number of row tiles
+  test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
+  test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);
+  test_gemm(7, EPI_RES_F32, OP_F16, 700, 1408, 1408, false);
   gemm_set_eight_phase(0);
   test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1408, false);   // 256 x 256 tile with the GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
