@@ -238,14 +238,14 @@ def main():
             "algorithmic_tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),
             "roofline": ({"bound": "mfma",
                           "kernel": ("folded cross-attention of one layer, video, the launches between the library's event pair (cross layer 0 of 6): "
-                                     + ("per-head Q' GEMM (gemm_kernel<64,64>) + Q' re-pack + fold_stream_kernel<scores> + row statistics + fold_stream_kernel<pv> "
+                                     + ("per-head Q' GEMM (gemm_kernel<128,128>, K = 64) + Q' re-pack + fold_stream_kernel<scores> + row statistics + fold_stream_kernel<pv> "
                                         "+ per-head context GEMM" if args.cross_mode == "fold_stream" else
-                                        "per-head Q' GEMM (gemm_kernel<64,64>) + batched scores GEMM (gemm_ws_kernel<176x384, EPI_SOFTPART>: exp2(s - tile max) in f16 "
+                                        "per-head Q' GEMM (gemm_kernel<128,128>, K = 64) + batched scores GEMM (gemm_ws_kernel<176x384, EPI_SOFTPART>: exp2(s - tile max) in f16 "
                                         "+ tile statistics) + " + ("softmax_rescale_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384>, encoder tokens as the K-major operand)"
                                                                     if args.cross_mode == "fold_rescale_pass" else
                                                                     "fold_rowfactor_kernel + batched P.enc GEMM (gemm_ws_kernel<176x384, PSC>: encoder tokens as the K-major "
                                                                     "operand, row factors applied to the P~ fragments in registers)")
-                                        + " + per-head context GEMM")),
+                                        + " + per-head context GEMM (gemm_k128_kernel<64,128>)")),
                           "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                           "avg_launch_ms": round(kv_step_ms, 4), "flops_per_launch": block_exec,
