@@ -8,10 +8,10 @@
 // One batched forward over ALL frames of a step (the reference calls the encoder T times at batch B):
 //   im2col -> patch GEMM (+ bias + position embedding in the epilogue) -> [CLS] rows
 //   39 x { LN -> QKV GEMM -> attention core -> projection GEMM + residual -> LN -> fc1 GEMM + GELU -> fc2 GEMM + residual }
-// 97 % of the flops are the four GEMMs per block at M = frames x 257 rows: the loader-wave kernels of gemm.hip (256 x 256 for
-// all four, the N = 1408 ones with a masked last column tile) with bias / GELU / residual fused: the residual GEMMs START
-// their accumulators at bias + residual, so their epilogue only stores.  The fp32 residual stream is updated in place and
-// IS the output; LayerNorms write the f16 operand of the next GEMM.
+// 97 % of the flops are the four GEMMs per block at M = frames x 257 rows: the eight-phase 256 x 256 kernel of gemm.hip (QKV, fc1;
+// the N = 1408 ones as full tiles plus a 128 x 512 tail tile per pair of row tiles, GemmProb::tile_cfg 8) with bias / GELU /
+// residual fused: the residual GEMMs START their accumulators at bias + residual, so their epilogue only stores.  The fp32
+// residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
 // Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
 // per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
 // MFMA steps; the zero columns add nothing to any dot product.
