@@ -147,7 +147,7 @@ static void order_ab(int rounds) {
     fflush(stdout);
   }
   gemm_set_tile_order(0);
-  gemm_set_eight_phase(0);
+  gemm_set_eight_phase(1);
 }
 
 // would split-K pay on the layer chain's residual GEMMs?  One problem over the whole K against two problems over half of it each
@@ -251,8 +251,68 @@ static void chain_ab(int rounds) {
   }
 }
 
+// Race screen of the eight-phase kernels at full size: the loader-wave kernel accumulates every output in the same order (K tile by K tile,
+// two 32-deep MFMA steps each), so the two must agree BIT FOR BIT; a tile read before its DMA landed shows up as a differing element.
+static void race_screen(int rounds) {
+  const int M = 1024 * 257;
+  std::mt19937 rng(9);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)1 << 24);
+  for (auto& v : h) v = (_Float16)d(rng);
+  _Float16 *A, *W;
+  float *bias, *R;
+  char *C0, *C1;
+  const size_t nA = (size_t)M * 6144, nW = (size_t)9216 * 1408, cbytes = (size_t)M * 9216 * 2;
+  CK(hipMalloc((void**)&A, nA * 2)); CK(hipMalloc((void**)&W, nW * 2)); CK(hipMalloc((void**)&C0, cbytes)); CK(hipMalloc((void**)&C1, cbytes));
+  for (size_t off = 0; off < nA; off += h.size()) CK(hipMemcpy(A + off, h.data(), std::min(h.size(), nA - off) * 2, hipMemcpyHostToDevice));
+  for (size_t off = 0; off < nW; off += h.size()) CK(hipMemcpy(W + off, h.data(), std::min(h.size(), nW - off) * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&bias, 16384 * 4)); CK(hipMemset(bias, 0, 16384 * 4));
+  CK(hipMalloc((void**)&R, (size_t)M * 1408 * 4)); CK(hipMemset(R, 0, (size_t)M * 1408 * 4));
+  struct S { const char* name; int N, K, epi, cfg; size_t out_bytes; };
+  const S shapes[] = {{"kvproj 263168x1408->9216 EPI_KV", 9216, 1408, EPI_KV, 0, (size_t)M * 9216 * 2},
+                      {"fc1 263168x1408->6144 EPI_GELU_OP", 6144, 1408, EPI_GELU_OP, 0, (size_t)M * 6144 * 2},
+                      {"fc2 263168x6144->1408 EPI_RES_F32, full + tail tiles", 1408, 6144, EPI_RES_F32, 8, (size_t)M * 1408 * 4}};
+  std::vector<char> ref, got;
+  for (auto& sh : shapes) {
+    GemmProb p{};
+    p.A = A; p.a = RowView{0, M, sh.K}; p.W = W; p.bias = bias; p.R = R; p.r = RowView{0, M, sh.N};
+    p.M = M; p.N = sh.N; p.K = sh.K;
+    if (sh.epi == EPI_KV) { p.kv_tokens = M / 32; p.kv_items = 32; p.kv_heads = 12; p.c = RowView{0, 1, 1}; }
+    else p.c = RowView{0, M, sh.N};
+    // reference: the loader-wave kernel (masked last column tile for N = 1408)
+    gemm_set_eight_phase(0);
+    GemmProb q = p;
+    q.C = C0;
+    if (sh.cfg == 8) { q.tile_cfg = 3; q.n_mask = 1; }
+    CK(hipMemset(C0, 0, sh.out_bytes));
+    if (launch_gemm(&q, 1, sh.epi, OP_F16, 0)) { printf("reference launch failed\n"); return; }
+    CK(hipDeviceSynchronize());
+    ref.resize(sh.out_bytes);
+    CK(hipMemcpy(ref.data(), C0, sh.out_bytes, hipMemcpyDeviceToHost));
+    gemm_set_eight_phase(1);
+    size_t bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+      GemmProb e = p;
+      e.C = C1;
+      if (sh.cfg == 8) e.tile_cfg = 8;
+      CK(hipMemset(C1, 0, sh.out_bytes));
+      if (launch_gemm(&e, 1, sh.epi, OP_F16, 0)) { printf("eight-phase launch failed\n"); return; }
+      CK(hipDeviceSynchronize());
+      got.resize(sh.out_bytes);
+      CK(hipMemcpy(got.data(), C1, sh.out_bytes, hipMemcpyDeviceToHost));
+      if (memcmp(got.data(), ref.data(), sh.out_bytes)) {
+        for (size_t i = 0; i < sh.out_bytes; i += 2) bad += got[i] != ref[i] || got[i + 1] != ref[i + 1];
+      }
+    }
+    printf("%-58s %d runs: %s (%zu differing 16-bit words)\n", sh.name, rounds, bad ? "MISMATCH" : "bit-identical to the loader-wave kernel", bad);
+    fflush(stdout);
+  }
+  gemm_set_eight_phase(1);
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "race")) { race_screen(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "chain")) { chain_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "splitk")) { splitk_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
