@@ -9,15 +9,16 @@ HBM: per GPU 32 clips, each clip = 32 video frames (32 x 257 = 8224 ViT-g tokens
 BASELINE "32-clip x 32-frame" shape) + 10 s of audio (496 BEATs tokens x 768), a
 32-token prompt.  Timed: modality LayerNorm -> video Q-Former -> audio Q-Former -> (N > 1: RCCL
 all-gather of the query embeddings) -> cosine scores -> fusion -> integer spans.  Nothing is skipped
-or cached between steps.  The ViT-g / BEATs encoders (stock PyTorch, not part of this build's
-kernels) are NOT in the timed region: the features are the synthetic input (BASELINE configs 1-4).
+or cached between steps.  The ViT-g / BEATs encoders are NOT in the timed region of `value`: the features
+are the synthetic input (BASELINE configs 1-4).  The ViT-g encode of the same 1024 frames -- on this build's own
+kernels (mra_vit_forward) and, beside it, stock PyTorch -- is timed separately and reported under `encode_stage`.
 Weak scaling: every GPU holds its own 32 clips of a 32*N-clip video; value = all clips / time.
 
 Also on the JSON line: `roofline` of the dominant kernels -- with the folded cross-attention (Kv >= 2048, the
 headline shape) the block of one cross layer (per-head Q' GEMM, scores + split-softmax statistics, P.enc, per-head
 context GEMM), timed inside the steps by an event pair the library records on the launch stream; `frac` is EXECUTED
 flops / dense f16 MFMA peak, the reference formulation's algorithmic flops are reported beside it -- and
-`cpu_baseline` (the CPU oracle on a bounded sample, median of three passes, rank 0, N = 1).
+`cpu_baseline` (the CPU oracle on a bounded sample, median of five passes, rank 0, N = 1).
 """
 from __future__ import annotations
 
@@ -68,7 +69,7 @@ def parse():
                     help="cross-attention formulation (auto = folded from Kv >= 2048; fold_stream / fold384: A/B variants)")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
-    ap.add_argument("--no-encode", action="store_true", help="skip the separately timed stock-PyTorch ViT-g encode stage")
+    ap.add_argument("--no-encode", action="store_true", help="skip the separately timed ViT-g encode stage")
     return ap.parse_args()
 
 
@@ -133,8 +134,8 @@ def main():
         out = step()
     fence()
     log("warm-up done")
-    # events around the dominant kernel (video K/V projection) inside every timed step, recorded by
-    # the library on the launch stream (= torch's current stream)
+    # events around the dominant kernels (folded path: the block of cross layer 0; K/V-cache path: the K/V projection GEMM) inside
+    # every timed step, recorded by the library on the launch stream (= torch's current stream)
     lib = _lib.lib()
     qf = model.video_Qformer
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -158,7 +159,8 @@ def main():
     value = n_total * args.steps / dt
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
-    # ---- roofline of the dominant kernel: the K/V projection GEMM of the video Q-Former ----
+    # ---- stand-alone timing of the K/V projection GEMM of the video Q-Former (the dominant kernel of the K/V-cache path; with the
+    #      folded path it is reported beside the block's roofline as kv_cache_mode_gemm) ----
     enc = qf.modality_ln(feats["video"])
     nb = int(lib.mra_kv_cache_bytes(qf._handle, n_local, kv["video"]))
     cache = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -207,7 +209,7 @@ def main():
     flops_step = sum(getattr(model, f"{m}_Qformer").flops(n_local, L, kv[m], True) for m in ("video", "audio"))   # reference formulation
     flops_exec = flops_step - (ncross * (block_alg - block_exec) if folded else 0.0)
 
-    # ---- the encode stage (row A1), timed SEPARATELY: stock PyTorch EVA ViT-g over every frame of the step ----
+    # ---- the encode stage (row A1), timed SEPARATELY: EVA ViT-g over every frame of the step (mra_vit_forward, and stock PyTorch beside it) ----
     encode = None
     if rank == 0 and world == 1 and not args.no_encode and args.workload == "clip32x32":
         encode = time_encode(dev, n_local, 32, dt / args.steps)
@@ -299,13 +301,25 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
                 torch.cuda.synchronize()
                 t = time.perf_counter() - t0
             assert y.shape == (chunk, 257, 1408)
+            if not bool(torch.isfinite(y).all()):
+                raise FloatingPointError(f"{backend}: non-finite encoder output")
+            # spot check of the timed batch: frames 0 / 1 / middle / last re-encoded as a 4-frame batch (other tile kernels, other
+            # positions in the batch) must reproduce their rows of the big batch
+            pick = [0, 1, chunk // 2, chunk - 1]
+            with torch.no_grad():
+                small = vit(x[pick])
+            spot = (small.float() - y[pick].float()).abs().max().item()
+            spot_bar = 5e-2 if backend == "hip" else 5e-1     # 39 blocks: f16-rounded intermediates on |y| ~ 30 (f16 residual / stock f16: coarser)
+            if not spot < spot_bar:
+                raise FloatingPointError(f"{backend}: 4-frame spot check differs from the timed batch by {spot:.3e}")
             fl = vit.flops_per_frame() * nframes
             out[backend] = {"what": ("EVA ViT-g/14 on mra_vit_forward (hand-written gfx950 kernels, f16 operands, fp32 residual)" if backend == "hip" else
                                      "the same with the residual stream in f16 (every add rounds to 16 bits, as LAVIS' precision=\"fp16\" encoder does)" if backend == "hip_f16_residual" else
                                      "EVA ViT-g/14, stock PyTorch f16 (SDPA + hipBLASLt)") + f", random weights, {nframes} frames in chunks of {chunk}",
                             "ms": round(t * 1e3, 1), "tflops": round(fl / t / 1e12, 1), "gflop_per_frame": round(vit_gf(fl, nframes), 1),
+                            "finite": True, "spot_check_max_abs_diff_4_frames": round(spot, 5),
                             "clips_per_s_encode_only": round(clips / t, 2), "clips_per_s_encode_plus_fuse_score": round(clips / (t + fuse_s), 2)}
-            del vit, x, y
+            del vit, x, y, small
             torch.cuda.empty_cache()
         except Exception as e:  # the encode stage is context, never a reason to lose the bench line
             out[backend] = {"error": repr(e)[:300]}
@@ -318,8 +332,8 @@ def vit_gf(total_flops, nframes):
 
 def cpu_baseline(args, kv, L):
     """The oracle (kind "port": a CPU restatement in torch fp32, all host threads) on the same workload, bounded to a few
-    clips so the default run stays within minutes.  Protocol (SURVEY 8d / BASELINE.md): one warm-up pass, then the MEDIAN
-    of three timed passes over the sample; the reference item shape (Kv 257 / 256) is timed the same way beside it."""
+    clips so the default run stays within minutes.  Protocol (SURVEY 8d / BASELINE.md section 3): one warm-up pass, then the MEDIAN
+    of FIVE timed passes over the sample; the reference item shape (Kv 257 / 256) is timed the same way beside it."""
     from mraudio_amd.models.xinstructblip import ENC_WIDTH
     from oracle import qformer_ref as O
 
@@ -329,7 +343,7 @@ def cpu_baseline(args, kv, L):
     cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
     ws = {"video": O.init_weights(cfgs["video"], seed=0), "audio": O.init_weights(cfgs["audio"], seed=1)}
 
-    def timed(n, kvs, passes=3):
+    def timed(n, kvs, passes=5):
         g = torch.Generator().manual_seed(1234)
         feats = {m: torch.randn(n, kvs[m], ENC_WIDTH[m], generator=g) for m in ("audio", "video")}
         ids = torch.randint(1000, 30000, (n, L), generator=g)
@@ -343,13 +357,13 @@ def cpu_baseline(args, kv, L):
                 ts.append(time.perf_counter() - t0)
         return sorted(ts)[len(ts) // 2], ts
 
-    # bounded samples: ~0.47 s per 32-frame clip on 16 threads -> 16 clips x 3 passes = ~23 s; reference items: 0.05 s each
-    n = args.cpu_clips if args.cpu_clips > 0 else (16 if args.workload == "clip32x32" else 128)
+    # bounded samples: ~0.47 s per 32-frame clip on 16 threads -> 10 clips x 5 passes = ~24 s; reference items: 0.05 s each
+    n = args.cpu_clips if args.cpu_clips > 0 else (10 if args.workload == "clip32x32" else 96)
     med, ts = timed(n, kv)
     out = {"value": round(n / med, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-           "sample": f"{n} clips of the same workload, torch fp32 oracle: 1 warm-up + 3 timed passes, median {med:.1f} s (passes {[round(t, 1) for t in ts]})"}
+           "sample": f"{n} clips of the same workload, torch fp32 oracle: 1 warm-up + 5 timed passes, median {med:.1f} s (passes {[round(t, 1) for t in ts]})"}
     if args.workload == "clip32x32":
-        n_ref = 96
+        n_ref = 64
         med_r, ts_r = timed(n_ref, {"video": 257, "audio": 256})
         out["reference_item_shape"] = {"value": round(n_ref / med_r, 2), "unit": "items/s",
                                        "sample": f"{n_ref} items at the reference's own item shape (Kv 257 video + 256 audio), same protocol, median {med_r:.1f} s"}

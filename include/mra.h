@@ -248,6 +248,15 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
 /* algorithmic flops of one forward over `frames` frames (2 per MAC) */
 double mra_vit_flops(mra_vit* h, int32_t frames);
 
+/* ---- diagnostics (no reference counterpart) ---------------------------------------------------------------
+ * Number of GEMM launches of one main loop ("family") with one epilogue since the library was loaded; read-only, the only
+ * process-wide state of the library.  Families (csrc/kernels.h GemmFamily): 0 / 1 two-buffer 64x64 / 128x128, 3 loader-wave 256x256,
+ * 4 eight-phase 256x256, 5 / 6 loader-wave 128x384 / 176x384 (folded cross-attention), 7 / 10 128-deep 64x128 / 64x64,
+ * 8 eight-phase 128x512 tail tile, 9 eight-phase full + tail tiles in one launch.  Epilogues (GemmEpi): 0 op-dtype, 1 GELU,
+ * 2 fp32 residual, 3 fp32, 4 K/V cache, 5 softmax partials, 6 / 7 GELU forward + tape / GELU backward, 8 op-dtype residual.
+ * Returns -1 for an unknown family / epilogue.  Used by the parity tests to state which kernel produced the numbers checked. */
+int64_t mra_debug_gemm_launches(int32_t family, int32_t epilogue);
+
 #ifdef __cplusplus
 }
 #endif

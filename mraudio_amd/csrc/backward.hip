@@ -593,8 +593,12 @@ size_t attn_bwd_lds_bytes(int q_rows) {   // the fp32 VALU kernel (kept for A/B:
   return sizeof(float) * ((size_t)nqb * QB * PADW + 2 * QB * PADW + 4 * KB * PADW + 2 * QB * (KB + 1) + 2 * nqb * QB);
 }
 
+#ifdef MRA_GEMM_EXPERIMENTS
 static int g_attn_bwd_valu = 0;
 void attn_bwd_force_valu(int on) { g_attn_bwd_valu = on; }
+#else
+constexpr int g_attn_bwd_valu = 0;   // the shipped library: the MFMA kernel, no switch
+#endif
 
 int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream) {
   if (a.items <= 0 || a.heads <= 0 || a.q_rows <= 0 || a.kv_len <= 0 || !a.lse) return -1;

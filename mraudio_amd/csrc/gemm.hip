@@ -22,6 +22,7 @@
 // remap so that the 32 concurrently running workgroups of one XCD share operand panels in its L2.
 // Other main loops that were tried and measured (ring, prefetch, flag hand-off ...) live in
 // tests/native/gemm_experiments.inc, outside the product tree and the shipped library; verdicts in DESIGN.md section 8.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -1080,10 +1081,26 @@ __global__ void __launch_bounds__(WGN* WGM * 64) gemm_k128_kernel(const GemmArgs
   }
 }
 
+// launches per (kernel family, epilogue) since the library was loaded: read-only diagnostics (mra_debug_gemm_launches) so that a parity
+// test can state WHICH main loop produced the numbers it checked
+std::atomic<long long> g_launches[GEMM_FAMILIES][16];
+inline int counted(int family, int epi, int rc) {
+  if (rc == 0 && family >= 0 && family < GEMM_FAMILIES && epi >= 0 && epi < 16) g_launches[family][epi].fetch_add(1, std::memory_order_relaxed);
+  return rc;
+}
+
+#ifdef MRA_GEMM_EXPERIMENTS
 int g_force_cfg = -1;
 int g_variant = 5;  // 5 (default): warp-specialised 256x256, two-buffer small tiles (128-deep for K >= 2048);
                     // 1: two-buffer loop everywhere; other values: gemm_experiments.inc (experiment builds only)
 unsigned long long* g_dbg = nullptr;
+int g_p8 = 1;       // the eight-phase kernel for the 256 x 256 tile when K / 64 is even (0: the loader-wave kernel, for A/B runs)
+int g_order = 0;
+#else
+// the shipped library: no switches, the defaults are constants
+constexpr int g_force_cfg = -1, g_variant = 5, g_p8 = 1, g_order = 0;
+constexpr unsigned long long* g_dbg = nullptr;
+#endif
 
 // hipFuncSetAttribute once per kernel and device (it is not a stream operation: keep it out of the
 // per-launch path and out of graph captures)
@@ -1131,7 +1148,6 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
   MRA_EPI_SWITCH((launch_k(gemm_ws_kernel<T, E>, a, 768, lds, stream)))
 }
 
-int g_p8 = 1;   // the eight-phase kernel for the 256 x 256 tile when K / 64 is even (0: the loader-wave kernel, for A/B runs and odd step counts)
 template <typename T>
 int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false) {
   constexpr size_t lds = 2 * (256 + 256) * 128;
@@ -1195,16 +1211,16 @@ int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
 
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
-  if (cfg == 3) return launch_ws_fold<T>(a, epi, stream);
-  if (cfg == 4) return launch_ws_pv<T>(a, epi, stream);
-  if (cfg == 5) return launch_k128<T, 64, 128, 2, 2>(a, epi, stream);   // 64 weight rows x 128 activation rows, 128-deep steps
-  if (cfg == 6) return launch_p8<T>(a, epi, stream, true);              // 128 weight rows x 512 activation rows, eight phases
+  if (cfg == 3) return counted(GF_WS_128x384, epi, launch_ws_fold<T>(a, epi, stream));
+  if (cfg == 4) return counted(GF_WS_176x384, epi, launch_ws_pv<T>(a, epi, stream));
+  if (cfg == 5) return counted(GF_K128_64x128, epi, launch_k128<T, 64, 128, 2, 2>(a, epi, stream));   // 64 weight rows x 128 activation rows, 128-deep steps
+  if (cfg == 6) return counted(GF_P8_TAIL, epi, launch_p8<T>(a, epi, stream, true));              // 128 weight rows x 512 activation rows, eight phases
   if (cfg == 7) {                                                        // N = 256 k + 128: full tiles + one 128 x 512 tail tile per pair of row tiles
     constexpr size_t ldst = 2 * (128 + 512) * 128;
     switch (epi) {
-      case EPI_RES_OP: return launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream);
-      case EPI_RES_F32: return launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream);
-      case EPI_F32: return launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream);
+      case EPI_RES_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream));
+      case EPI_RES_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream));
+      case EPI_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream));
       default: return -2;
     }
   }
@@ -1220,21 +1236,21 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
       for (int g = 0; g < a.ngroups; ++g) even = even && (a.p[g].K / 64) % 2 == 0 && a.p[g].K >= 128;
       if (g_p8 && even) {
         const int rc = launch_p8<T>(a, epi, stream);
-        if (rc != -100) return rc;
+        if (rc != -100) return counted(GF_P8_256, epi, rc);
       }
-      return launch_ws<T>(a, epi, stream);
+      return counted(GF_WS_256, epi, launch_ws<T>(a, epi, stream));
     }
     if (cfg == 0) {
       // 128-deep steps pay on the 64x64 tile once the K loop is long (FFN down-projection, K = 3072:
       // 367 -> 460 TF/s); at K = 768 the launch is prologue/epilogue-bound and nothing changes
       bool k128 = true;
       for (int g = 0; g < a.ngroups; ++g) k128 = k128 && a.p[g].K % 128 == 0 && a.p[g].K >= 2048;
-      if (k128) return launch_k128<T, 64, 64, 2, 2>(a, epi, stream);
+      if (k128) return counted(GF_K128_64x64, epi, launch_k128<T, 64, 64, 2, 2>(a, epi, stream));
     }
   }
-  if (cfg == 2) return launch_v1<T, 256, 256, 2, 4>(a, epi, stream);
-  if (cfg == 1) return launch_v1<T, 128, 128, 2, 2>(a, epi, stream);
-  return launch_v1<T, 64, 64, 2, 2>(a, epi, stream);
+  if (cfg == 2) return counted(GF_V1_256, epi, launch_v1<T, 256, 256, 2, 4>(a, epi, stream));
+  if (cfg == 1) return counted(GF_V1_128, epi, launch_v1<T, 128, 128, 2, 2>(a, epi, stream));
+  return counted(GF_V1_64, epi, launch_v1<T, 64, 64, 2, 2>(a, epi, stream));
 }
 
 constexpr int kTile[3] = {64, 128, 256};
@@ -1244,12 +1260,17 @@ constexpr int kTileM[8] = {64, 128, 256, 384, 384, 128, 512, 256};   // activati
 }  // namespace
 
 
+long long gemm_launch_count(int family, int epi) {
+  if (family < 0 || family >= GEMM_FAMILIES || epi < 0 || epi >= 16) return -1;
+  return g_launches[family][epi].load(std::memory_order_relaxed);
+}
+#ifdef MRA_GEMM_EXPERIMENTS
 void gemm_force_config(int cfg) { g_force_cfg = cfg; }
 void gemm_force_variant(int v) { g_variant = v; }
-static int g_order = 0;
 void gemm_set_tile_order(int order) { g_order = order; }
 void gemm_set_eight_phase(int on) { g_p8 = on; }
 void gemm_set_debug_buffer(unsigned long long* p) { g_dbg = p; }
+#endif
 
 int gemm_pick_config(const GemmProb* probs, int ngroups) {
   if (g_force_cfg >= 0) return g_force_cfg;

@@ -97,12 +97,29 @@ struct GemmArgs {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream);
 // which tile config launch_gemm would pick (for tests / DESIGN.md): 0 = 64x64, 1 = 128x128, 2 = 256x256
 int gemm_pick_config(const GemmProb* probs, int ngroups);
+// Main loops ("families") launch_gemm dispatches to, and a read-only launch counter per (family, epilogue) since the library was
+// loaded (mra_debug_gemm_launches in include/mra.h): parity tests use it to state which kernel produced the numbers they checked.
+enum GemmFamily {
+  GF_V1_64 = 0, GF_V1_128 = 1, GF_V1_256 = 2,   // gemm_kernel two-buffer loop (256: experiment builds only)
+  GF_WS_256 = 3,                                // gemm_ws_kernel 256 x 256 (odd number of K steps)
+  GF_P8_256 = 4,                                // gemm_p8_kernel eight-phase 256 x 256
+  GF_WS_128x384 = 5, GF_WS_176x384 = 6,         // loader-wave tiles of the folded cross-attention
+  GF_K128_64x128 = 7,                           // gemm_k128_kernel, 128-deep steps
+  GF_P8_TAIL = 8, GF_P8_MIXED = 9,              // eight-phase 128 x 512 tail tile; full tiles + tail tile in one launch
+  GF_K128_64x64 = 10,
+  GEMM_FAMILIES = 11
+};
+long long gemm_launch_count(int family, int epi);
+#ifdef MRA_GEMM_EXPERIMENTS
+// Process-global A/B switches: compiled ONLY into tests/native/libmra_hip_exp.so (the experiment library of tests/native/gemm_bench and
+// kernel_check_exp); the shipped libmra_hip.so has no mutable global state besides the launch counters above.
 void gemm_force_config(int cfg);  // -1 = automatic (default)
 void gemm_set_debug_buffer(unsigned long long* dev_buf);  // variant 4 (stamped v1) writes 4 u64 per wave
 void gemm_set_eight_phase(int on);         // 256 x 256 launches with an even number of K steps on gemm_p8_kernel (A/B switch)
 void gemm_set_tile_order(int order);      // overrides GemmProb::order for every later launch when != 0 (A/B runs)
 void gemm_force_variant(int v);   // 5 = default (warp-specialised 256x256, two-buffer small tiles); 0 ring, 1 two-buffer,
                                   // 2 +L2 prefetch, 3 +spread DMA issue, 4 stamped diagnostic -- kept for A/B runs
+#endif
 
 // ---- backward-pass GEMMs ------------------------------------------------------------------------
 // dW[n][k] (+)= sum_m dY[m][n] * X[m][k].  dY and X are given as 64-column blocks: block b of dY starts at
@@ -155,7 +172,9 @@ struct AttnBwdArgs {
   float scale;
 };
 int launch_attn_bwd(const AttnBwdArgs& a, int op_dtype, hipStream_t stream);
-void attn_bwd_force_valu(int on);   // A/B switch: the first (fp32 VALU) kernel instead of the MFMA one
+#ifdef MRA_GEMM_EXPERIMENTS
+void attn_bwd_force_valu(int on);   // A/B switch (experiment library only): the first (fp32 VALU) kernel instead of the MFMA one
+#endif
 int launch_embed_bwd(const float* demb, const long long* ids, int items, int L, int Q, int H, int vocab, float* dquery, float* dpos,
                      float* dword, hipStream_t stream);
 int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, hipStream_t stream);

@@ -229,6 +229,7 @@ extern "C" {
 
 const char* mra_last_error(void) { return g_err.c_str(); }
 const char* mra_version(void) { return "mraudio_amd 0.1 (gfx950)"; }
+int64_t mra_debug_gemm_launches(int32_t family, int32_t epilogue) { return gemm_launch_count(family, epilogue); }
 
 void mra_cfg_default(mra_cfg* c, int32_t enc_width) {
   c->hidden = 768;

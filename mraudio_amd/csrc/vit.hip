@@ -400,8 +400,11 @@ size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames) {
   if (!h || frames <= 0) return 0;
   const size_t M = (size_t)frames * h->S;
   const size_t wide = std::max<size_t>(std::max<size_t>(h->nqkv, h->cfg.mlp), h->kpad);
-  // r16: the fp32 embeddings are staged behind the patches inside the wide buffer (patches M x kpad x 2 + M x dim x 4 <= M x wide x 2)
-  return align_up(M * h->cfg.dim * 2) + align_up(M * wide * 2) + 4096;
+  // the wide buffer: patches, then Q|K|V, then the fc1 activation; with the residual stream in the operand dtype the fp32 embeddings
+  // are staged behind the patches inside it, so it must also hold patches + M x dim x 4 (for small patches / large images that exceeds M x wide x 2)
+  size_t big = M * wide * 2;
+  if (h->cfg.residual_dtype != MRA_F32) big = std::max(big, align_up((size_t)frames * h->np * h->np * h->kpad * 2) + M * h->cfg.dim * 4);
+  return align_up(M * h->cfg.dim * 2) + align_up(big) + 4096;
 }
 
 int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, void* out_, void* workspace, size_t workspace_bytes, void* stream_) {

@@ -246,23 +246,35 @@ class XInstructBLIP(nn.Module):
             raise RuntimeError(f"Error(s) in loading state_dict for XInstructBLIP: missing {missing}, unexpected {unexpected}")
         return _IncompatibleKeys(missing, unexpected)
 
-    def load_checkpoint(self, filename, strict: bool = False, **kwargs):
-        """Weights-only load of a ``.pth`` holding the reference's key names (``{m}_Qformer.*``, ``{m}_query_tokens``,
-        ``{m}_ln.*``, ``{m}_llm_proj.*``; optionally under ``"model"``).  Not strict by default, like the reference's
-        own loader (``:759-816`` returns the incompatible keys); raises when NOTHING in the file matched."""
+    def _load_file(self, filename, strict: bool):
         ckpt = torch.load(filename, map_location="cpu", weights_only=True)
         sd = ckpt["model"] if "model" in ckpt else ckpt
-        msg = self.load_state_dict(sd, strict=strict)
         mine = [k for k in sd if k.startswith(tuple(f"{m}_" for m in self.modalities))]
         if not mine:
             raise RuntimeError(f"{filename}: no key of this model's modalities {self.modalities} found")
+        msg = self.load_state_dict(sd, strict=strict)
         self.weights_source = f"checkpoint {filename}"
         if msg.missing_keys:
+            self.weights_source += f" ({len(msg.missing_keys)} parameters NOT in the file keep their previous values)"
             logging.warning("%s: %d parameters keep their previous values (first: %s)", filename, len(msg.missing_keys), msg.missing_keys[:3])
         if isinstance(self.tokenizer, HashTokenizer):
             logging.warning("checkpoint weights are used with the offline HashTokenizer: token ids do NOT match the "
                             "bert-base-uncased vocabulary the checkpoint was trained with")
         return msg
+
+    def load_checkpoint(self, filename, strict: bool = True, **kwargs):
+        """Weights-only load of a finetuned ``.pth`` holding the reference's key names (``{m}_Qformer.*``, ``{m}_query_tokens``,
+        ``{m}_ln.*``, ``{m}_llm_proj.*``; optionally under ``"model"``).  STRICT, like the reference's ``load_checkpoint``
+        (``:759-767``: "this should expect no mismatch in the model keys and the checkpoint keys"): a file that lacks any
+        Q-Former / LayerNorm / projection parameter of this model raises instead of silently keeping the synthetic init
+        (``llm_model.*`` and encoder keys are not part of this path and are ignored).  ``strict=False`` is an explicit opt-in
+        (or use ``load_from_pretrained``); the number of missing parameters then shows in ``weights_source``."""
+        return self._load_file(filename, strict)
+
+    def load_from_pretrained(self, filename, **kwargs):
+        """The reference's non-strict loader (``:749-757``, ``load_state_dict(strict=False)``): partial files are accepted, what is
+        missing keeps its previous values and is counted in ``weights_source``."""
+        return self._load_file(filename, False)
 
     def get_optimizer_params(self, weight_decay, lr_scale=1):
         """LAVIS ``BaseModel.get_optimizer_params`` semantics (reference ``:818-820``): parameters that

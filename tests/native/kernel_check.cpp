@@ -86,8 +86,8 @@ static void report(const std::string& name, double err, double tol) {
 static long long voff(const RowView& v, int m) { return (long long)(m / v.rpi) * v.item_stride + (long long)(m % v.rpi) * v.ld; }
 
 // ------------------------------------------------------------------------------------------------
+static int g_test_order = 0;   // GemmProb::order of the next test_gemm problems (tile walk)
 static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views, int groups = 1) {
-  gemm_force_config(cfg);
   // activations live in [items, S, K] with the rows of interest at [:, off:off+rpi]
   const int rpi = views ? 5 : (M > 0 ? M : 1);
   const int S = views ? 9 : rpi, off = views ? 3 : 0;
@@ -142,6 +142,8 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
     p.M = q == 0 ? M : (M > 3 ? M - 3 : M);
     p.N = N;
     p.K = K;
+    p.tile_cfg = cfg >= 0 ? cfg + 1 : 0;   // per problem: the shipped library has no global switches
+    p.order = g_test_order;
     if (epi == EPI_RES_F32 || epi == EPI_F32) {
       p.C = dC32[q]->p + (size_t)off * ldc;
       p.c = x.cv;
@@ -205,7 +207,6 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
   for (auto p : dR) delete p;
   for (auto p : dC16) delete p;
   for (auto p : dC32) delete p;
-  gemm_force_config(-1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -317,7 +318,6 @@ static void test_attention(int op, int items, int heads, int q_rows, int kv_len,
 
 // P . enc form: W given K-major ([k_rows][ldw] row-major, columns = output n), K padded beyond k_rows where A is zero
 static void test_gemm_kmajor(int op, int M, int N, int K, int k_rows, int batch) {
-  gemm_force_config(-1);
   const int ldw = N + 16;
   std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * k_rows * ldw);
   for (size_t b = 0; b < (size_t)batch; ++b)
@@ -348,7 +348,6 @@ static void test_gemm_kmajor(int op, int M, int N, int K, int k_rows, int batch)
 
 // n_mask: N not a multiple of the tile, plain [M][N] output rows; columns past N are neither read (bias, residual) nor stored
 static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
-  gemm_force_config(-1);
   std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K);
   for (auto& v : A) v = to_op(frand(), op);
   for (auto& v : W) v = to_op(frand(0.05f), op);
@@ -360,7 +359,7 @@ static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   GemmProb p;
   memset(&p, 0, sizeof(p));
   p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = dB.p; p.R = dR.p; p.r = RowView{0, M, N};
-  p.C = dC.p; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.n_mask = 1; p.tile_cfg = cfg + 1;
+  p.C = dC.p; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.n_mask = 1; p.tile_cfg = cfg + 1; p.order = g_test_order;
   const int rc = launch_gemm(&p, 1, epi, op, 0);
   CK(hipDeviceSynchronize());
   std::vector<float> c = dC.get();
@@ -381,7 +380,6 @@ static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
 // P[m][k] = op(float(P~[m][k]) * g[tile(k)][m]), then the product in double.  A is zero from column kv on; the factor slots past the last tile
 // reuse its (finite) factors.
 static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
-  gemm_force_config(-1);
   const int ntiles = (kv + 175) / 176, K = ((std::max((kv + 127) / 128 * 128, ntiles * 176) + 127) / 128) * 128, ldw = N;
   std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * kv * ldw);
   std::vector<float> G((size_t)batch * ntiles * 512, 123.f);
@@ -424,7 +422,6 @@ static void test_gemm_pscale(int op, int M, int N, int kv, int batch) {
 // scores of the folded path: batched, ragged N, EPI_SOFTPART -- P~[m][n] = exp2(alpha s - tile max) in the operand dtype, tile maxima and
 // tile sums (of the ROUNDED P~); columns past N inside the last tile are zero.
 static void test_gemm_softpart(int op, int M, int kv, int K, int batch) {
-  gemm_force_config(-1);
   const int ntiles = (kv + 175) / 176, ldp = ntiles * 176 + 16;
   const float alpha = 0.125f * 1.4426950408889634f;
   std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * kv * K);
@@ -474,7 +471,6 @@ static void test_gemm_softpart(int op, int M, int kv, int K, int batch) {
 
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
 static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
-  gemm_force_config(-1);
   const int t = cfg == 0 ? 64 : (cfg == 2 ? 256 : (cfg == 4 ? 176 : 128));   // weight rows per tile (config 3: 128 x 384, 4: 176 x 384)
   const int ldc = (N + t - 1) / t * t;                       // C rows hold whole tiles
   std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * N * K);
@@ -932,9 +928,13 @@ static void test_attn_bwd(int items, int heads, int q_rows, int kv_len, bool sel
   b.k_item_stride = f.k_item_stride; b.k_head_stride = f.k_head_stride; b.v_item_stride = f.v_item_stride; b.v_head_stride = f.v_head_stride;
   b.k_ld = f.k_ld; b.v_ld = f.v_ld; b.mask = f.mask; b.mask_ld = f.mask_ld; b.lse = dlse.p;
   b.items = items; b.heads = heads; b.q_rows = q_rows; b.kv_len = kv_len; b.scale = 0.125f;
+#ifdef MRA_GEMM_EXPERIMENTS
   attn_bwd_force_valu(valu ? 1 : 0);
+#endif
   rc |= launch_attn_bwd(b, op, 0);
+#ifdef MRA_GEMM_EXPERIMENTS
   attn_bwd_force_valu(0);
+#endif
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> rQ = gQ.get(), rK = gK.get(), rV = gV.get();
   std::vector<float> lse = dlse.get();
@@ -1017,8 +1017,10 @@ int main(int argc, char** argv) {
   test_attn_bwd(1, 12, 32, 1000, false);
   test_attn_bwd(2, 2, 41, 41, true, false, OP_BF16);
   test_attn_bwd(2, 2, 32, 100, false, false, OP_BF16);
-  test_attn_bwd(3, 2, 45, 45, true, true);      // the fp32 VALU kernel (A/B switch)
+#ifdef MRA_GEMM_EXPERIMENTS
+  test_attn_bwd(3, 2, 45, 45, true, true);      // the fp32 VALU kernel (A/B switch, experiment library only)
   test_attn_bwd(3, 2, 32, 257, false, true);
+#endif
   test_ln_rows(OP_F16);
   test_ln_rows(OP_BF16);
   test_modality_ln(0, 1408);
@@ -1040,7 +1042,6 @@ int main(int argc, char** argv) {
   }
   test_gemm(-1, EPI_OP, OP_F16, 300, 768, 1408, false);  // automatic config
   // the eight-phase 256 x 256 kernel (even K / 64): every epilogue, ragged M, row views, two problems, K = 128 (one pair) .. 1408
-  gemm_set_eight_phase(1);
   test_gemm(2, EPI_OP, OP_F16, 2 * 256 + 37, 512, 128, true);
   test_gemm(2, EPI_KV, OP_F16, 2100, 1536, 1408, false);
   test_gemm(2, EPI_GELU_OP, OP_F16, 700, 256, 1408, true);
@@ -1058,14 +1059,20 @@ int main(int argc, char** argv) {
   test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);
   test_gemm(7, EPI_RES_F32, OP_F16, 700, 1408, 1408, false);
-  gemm_set_eight_phase(0);
-  test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1408, false);   // 256 x 256 tile with the GELU epilogue, pre-activations out to |x| ~ 6
+  // an odd number of K steps takes the loader-wave 256 x 256 kernel (8 compute + 4 loader waves)
+  test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1344, false);   // GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
-  gemm_set_tile_order(8);   // column-fastest panels (the ViT's N = 1408 GEMMs)
+  test_gemm(2, EPI_RES_F32, OP_F16, 2 * 256 + 37, 512, 320, true, 2);
+  test_gemm(2, EPI_KV, OP_F16, 256 + 10, 512, 64, false);
+  test_gemm(2, EPI_OP, OP_BF16, 300, 512, 192, false);
+  test_gemm(2, EPI_F32, OP_F16, 300, 256, 704, false);
+  g_test_order = 8;   // column-fastest panels (the ViT's N = 1408 GEMMs)
   test_gemm(2, EPI_RES_F32, OP_F16, 1300, 512, 320, true, 2);
+  test_gemm(2, EPI_RES_F32, OP_F16, 1300, 512, 384, true, 2);
   test_gemm_masked(2, EPI_RES_F32, OP_F16, 1500, 1408, 192);
+  test_gemm_masked(2, EPI_RES_F32, OP_F16, 1500, 1408, 256);
   test_gemm(1, EPI_OP, OP_F16, 700, 640, 128, true);
-  gemm_set_tile_order(0);
+  g_test_order = 0;
   test_gemm_masked(2, EPI_RES_F32, OP_F16, 700, 352, 128);   // N = 1.4 column tiles of 256, the tail is neither read nor stored
   test_gemm_masked(2, EPI_F32, OP_F16, 300, 1408, 192);
   test_gemm_masked(1, EPI_RES_F32, OP_BF16, 200, 200, 64);
@@ -1098,6 +1105,11 @@ int main(int argc, char** argv) {
   test_fold_stream(2, 700, 704, 12.f);      // peaked rows: tile factors spread over many powers of two
   test_fold_stream(1, 1000, 704, 60.f);     // near one-hot rows: most tile factors flush to zero
   test_fold_stream(3, 176, 1408, 2.f);      // exactly one tile, the video width
+#ifdef MRA_GEMM_EXPERIMENTS   // kernel_check_exp (links tests/native/libmra_hip_exp.so): the A/B main loops of gemm_experiments.inc
+  gemm_set_eight_phase(0);                               // the loader-wave kernel on an even number of K steps
+  test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1408, false);
+  test_gemm(2, EPI_KV, OP_F16, 2100, 1536, 1408, false);
+  gemm_set_eight_phase(1);
   gemm_force_variant(1);                                 // the two-buffer main loop kept for A/B runs
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int t = cfg == 0 ? 64 : (cfg == 1 ? 128 : 256);
@@ -1157,6 +1169,7 @@ int main(int argc, char** argv) {
   test_gemm(2, EPI_OP, OP_F16, 300, 512, 64, false);     // K = 64: fewer slots than the ring holds
   test_gemm(0, EPI_OP, OP_F16, 100, 128, 3072, false);   // long K on the 8-slot ring
   gemm_force_variant(5);
+#endif
 
   // attention
   test_attention(OP_F16, 5, 3, 45, 45, true, 1);     // self, ragged masks, 2 query blocks (13 live rows in the 2nd)

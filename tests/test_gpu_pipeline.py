@@ -121,3 +121,13 @@ def test_checkpoint_argument_loads_the_reference_key_names(tmp_path):
     torch.save({"llm_model.weight": torch.zeros(2)}, bogus)
     with pytest.raises(RuntimeError):
         XInstructBLIP(seed=0, device=dev, checkpoint=str(bogus))
+    # load_checkpoint is STRICT like the reference's (models/xinstructblip.py:759-767); a partial file is only accepted
+    # through the explicit non-strict loader (reference :749-757), and what it lacks is counted in weights_source
+    partial = tmp_path / "partial.pth"
+    torch.save({k: v.cpu() for k, v in src.state_dict().items() if k.startswith("video_ln")}, partial)
+    with pytest.raises(RuntimeError):
+        XInstructBLIP(seed=0, device=dev, checkpoint=str(partial))
+    loose = XInstructBLIP(seed=0, device=dev)
+    msg = loose.load_from_pretrained(str(partial))
+    assert msg.missing_keys and "NOT in the file" in loose.weights_source
+    assert torch.equal(loose.video_ln.weight.cpu(), src.video_ln.weight.cpu())

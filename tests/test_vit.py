@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from mraudio_amd.models.eva_vit import EvaViTg
-from tools.make_vit_golden import DEPTH, ROWS, WEIGHT_SEED, hf_reference, make_frames
+from tools.make_vit_golden import DEPTH, FRAMES, FULL_DEPTH, FULL_INPUT_SEED, FULL_WEIGHT_SEED, ROWS, WEIGHT_SEED, hf_reference, make_frames
 
 
 @pytest.fixture(scope="module")
@@ -45,3 +45,18 @@ def test_vit_matches_hf_live_and_the_name_map_round_trips(vit):
     sd["encoder.layers.0.self_attn.qkv.bias"] = sd["encoder.layers.0.self_attn.qkv.bias"] + 1.0
     with pytest.raises(ValueError):
         other.load_hf_state_dict(sd)                                         # a key bias cannot be represented
+
+
+def test_full_depth_restatement_matches_the_committed_39_layer_hf_vectors(golden_dir):
+    """The 39-block encoder bench.py times: the restatement against ``tests/golden/vit_g_d39.npz`` (HF ``InstructBlipVisionModel``,
+    39 layers, made by ``tools/make_vit_golden.py full``).  ~30 s of seeded weight drawing + ~1 TFLOP of fp32 CPU work."""
+    gold = np.load(os.path.join(golden_dir, "vit_g_d39.npz"))
+    meta = json.loads(str(gold["meta"]))
+    assert meta["depth"] == FULL_DEPTH and meta["weight_seed"] == FULL_WEIGHT_SEED and meta["input_seed"] == FULL_INPUT_SEED
+    torch.set_num_threads(8)
+    vit = EvaViTg(depth=FULL_DEPTH).eval().init_seeded_(FULL_WEIGHT_SEED)
+    with torch.no_grad():
+        y = vit(make_frames(FRAMES, FULL_INPUT_SEED))
+    assert np.abs(y[:, ROWS].numpy() - gold["rows"]).max() < 5e-4            # fp32 on both sides, |y| <= 26, 39 blocks
+    assert np.abs(y.sum(-1).numpy() - gold["token_sum"]).max() < 5e-2
+    assert (np.abs(y.pow(2).sum(-1).numpy() - gold["token_sq_sum"]) / gold["token_sq_sum"]).max() < 1e-4

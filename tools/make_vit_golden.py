@@ -10,6 +10,7 @@ output BEFORE HF's ``post_layernorm`` (that LayerNorm is the reference's separat
 per-token checksums of all 257 tokens.
 
     python tools/make_vit_golden.py        # writes tests/golden/vit_g.npz
+    python tools/make_vit_golden.py full   # writes tests/golden/vit_g_d39.npz (all 39 blocks, ~1 TFLOP of fp32 CPU work, ~9 GB of RAM)
 """
 from __future__ import annotations
 
@@ -25,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 DEPTH, WEIGHT_SEED, INPUT_SEED, FRAMES = 3, 5, 6, 2
 ROWS = [0, 1, 128, 256]
+# the full 39-block encoder (what bench.py times): 2 frames, rows + per-token checksums only -> tests/golden/vit_g_d39.npz
+FULL_DEPTH, FULL_WEIGHT_SEED, FULL_INPUT_SEED = 39, 11, 12
 
 
 def make_frames(n: int = FRAMES, seed: int = INPUT_SEED) -> torch.Tensor:
@@ -50,6 +53,21 @@ if __name__ == "__main__":
     from mraudio_amd.models.eva_vit import EvaViTg
 
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        vit = EvaViTg(depth=FULL_DEPTH).eval().init_seeded_(FULL_WEIGHT_SEED)
+        frames = make_frames(FRAMES, FULL_INPUT_SEED)
+        ref = hf_reference(vit, frames)
+        with torch.no_grad():
+            own = vit(frames)
+        print("depth 39, restatement vs HF: max|d|", (own - ref).abs().max().item(), "on |y| max", ref.abs().max().item(), "rms", ref.pow(2).mean().sqrt().item())
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "vit_g_d39.npz"),
+                            meta=np.array(json.dumps(dict(depth=FULL_DEPTH, weight_seed=FULL_WEIGHT_SEED, input_seed=FULL_INPUT_SEED, frames=FRAMES, rows=ROWS,
+                                                          source="transformers InstructBlipVisionModel, 39 layers, hidden_states[-1] (before post_layernorm)"))),
+                            rows=ref[:, ROWS].numpy().astype(np.float32),
+                            token_sum=ref.sum(-1).numpy().astype(np.float32), token_abs_sum=ref.abs().sum(-1).numpy().astype(np.float32),
+                            token_sq_sum=ref.pow(2).sum(-1).numpy().astype(np.float32))
+        print("wrote tests/golden/vit_g_d39.npz", tuple(ref.shape))
+        sys.exit(0)
     vit = EvaViTg(depth=DEPTH).eval().init_seeded_(WEIGHT_SEED)
     frames = make_frames()
     ref = hf_reference(vit, frames)
