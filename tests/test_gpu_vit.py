@@ -196,7 +196,7 @@ def test_benchmarked_batch_of_1024_frames(depth2, dev):
     dself = (y32.view(8, 4, 257, 1408) - y32[:4]).abs().max().item()
     print(f"vit 1024 frames: max|d| vs the 32-frame batch {d32:.3e} (32-frame batch vs itself {dself:.3e}), vs the 4-frame batch {d4:.3e}")
     assert d32 <= 1e-5 and dself <= 1e-5          # same kernels: position in the batch must not matter
-    assert d4 < 5e-3                              # other tile kernels round intermediate f16 activations differently
+    assert d4 <= 1e-4                             # other tile kernels (128 x 128 two-buffer loop), same K order: measured 0.0 on MI355X (r03a)
     w4 = want[:4]
     assert (big[255].cpu() - w4).abs().max().item() < 2e-2 and (big[128].cpu() - w4).abs().max().item() < 2e-2   # and it is the right answer
 
@@ -205,7 +205,7 @@ def test_full_depth_39_blocks_against_the_hf_fixture(dev, golden_dir):
     """All 39 blocks (what bench.py's encode stage times) against ``tests/golden/vit_g_d39.npz`` (transformers
     ``InstructBlipVisionModel`` with 39 layers on the seeded weights, ``tools/make_vit_golden.py full``): rows 0 / 1 / 128 / 256 of
     both frames and the per-token checksums of all 514 tokens, for both residual modes.  Error growth over depth is measured
-    against the fixture's own scale (|y| max 25.7, rms 5.3) and printed; the bars below are 2 x what MI355X measured (r03)."""
+    against the fixture's own scale (|y| max 25.7 over all tokens, 23.0 on the stored rows; rms 5.3) and printed; the bars below are 2 x what MI355X measured (r03a)."""
     gold = np.load(os.path.join(golden_dir, "vit_g_d39.npz"))
     meta = json.loads(str(gold["meta"]))
     assert meta["depth"] == FULL_DEPTH == 39 and meta["rows"] == ROWS
@@ -229,7 +229,10 @@ def test_full_depth_39_blocks_against_the_hf_fixture(dev, golden_dir):
         d_sq = np.abs(y.pow(2).sum(-1).numpy() - gold["token_sq_sum"]) / gold["token_sq_sum"]
         report[residual] = dict(max_abs=float(d_rows.max()), rel=rel_rows, token_sum=float(d_sum), token_sq_rel=float(d_sq.max()))
     print(f"vit depth 39 vs HF (|y| max {scale:.1f}, rms {rms:.2f}):", report)
-    # depth 3 measures 2e-2 / 2e-3 (fp32 residual) and 4e-2 / 4e-3 (f16 adds) at |y| <= 7; 39 blocks on |y| <= 26:
-    assert report["fp32"]["max_abs"] < 8e-2 and report["fp32"]["rel"] < 4e-3, report
-    assert report["op"]["max_abs"] < 4e-1 and report["op"]["rel"] < 2e-2, report
-    assert report["fp32"]["token_sq_rel"] < 5e-3 and report["op"]["token_sq_rel"] < 3e-2, report
+    # Measured on MI355X (gpurun_out/r03a/vit.log), 39 blocks, |y| max 23, rms 5.3: fp32 residual max|d| 1.87e-2, rel 8.1e-4
+    # (depth 3: 2e-2 / 2e-3 bars on |y| <= 7 -- the relative error does NOT grow with depth: rounding errors of the f16 operands are
+    # independent per block and the stream's norm grows as fast as they accumulate); f16 residual (78 rounded adds) max|d| 7.2e-2,
+    # rel 1.9e-3.  Bars = 2 x measured.
+    assert report["fp32"]["max_abs"] < 4e-2 and report["fp32"]["rel"] < 1.6e-3, report
+    assert report["op"]["max_abs"] < 1.5e-1 and report["op"]["rel"] < 4e-3, report
+    assert report["fp32"]["token_sq_rel"] < 3e-4 and report["op"]["token_sq_rel"] < 8e-4, report
