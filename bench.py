@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--cross-mode", default="auto", choices=["auto", "kv_cache", "fold", "fold_stream", "fold384", "fold_rescale_pass"],
                     help="cross-attention formulation (auto = folded from Kv >= 2048; fold_stream / fold384: A/B variants)")
+    ap.add_argument("--cross-precision", default="op", choices=["op", "split"],
+                    help="precision of the cross-attention score chain: op = f16 / bf16 operands (default); split = hi + lo pairs (~22 bits) for sharply attending weights")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed ViT-g encode stage")
@@ -110,6 +112,8 @@ def main():
     model.prioritize_heavy = not args.no_priority
     for m in ("video", "audio"):
         getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
+        if args.cross_precision != "op":
+            getattr(model, f"{m}_Qformer").set_cross_precision(args.cross_precision)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = {m: torch.randn(n_local, kv[m], ENC_WIDTH[m], generator=g, device=dev, dtype=torch.float16) for m in ("video", "audio")}
     ids = torch.randint(1000, 30000, (n_local, L), generator=g, device=dev)
@@ -177,7 +181,7 @@ def main():
     ncross, H, E = 6, 768, ENC_WIDTH["video"]
     kv_flops = 2.0 * n_local * kv["video"] * E * (ncross * 2 * H)
     Q, R = 32, 12 * 32
-    folded = args.cross_mode in ("fold", "fold_stream", "fold384", "fold_rescale_pass") or (args.cross_mode == "auto" and kv["video"] >= 2048)
+    folded = args.cross_precision == "split" or args.cross_mode in ("fold", "fold_stream", "fold384", "fold_rescale_pass") or (args.cross_mode == "auto" and kv["video"] >= 2048)
     if folded:
         # folded cross-attention: the library's event pair brackets the launches of cross layer 0.  Executed work = the
         # re-associated products actually run (that is what `frac` prices); algorithmic work = what the reference
@@ -234,7 +238,7 @@ def main():
                 "parallelism": f"clip-shard x{world}" + (" + RCCL all-gather of query embeddings" if world > 1 else ""),
                 "encoders": "not part of value (synthetic features stand in for ViT-g / BEATs outputs); the ViT-g encode of the same frames is timed separately under encode_stage",
                 "weights": "synthetic BERT init, seed 0",
-                "cross_attention": "folded" if folded else "kv_cache",
+                "cross_attention": "folded" if folded else "kv_cache", "cross_precision": args.cross_precision,
             },
             "executed_tflops_per_gpu": round(flops_exec * args.steps / dt / 1e12, 1),
             "algorithmic_tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),

@@ -147,6 +147,18 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop);
  *      read and write of P per layer: kept as the measured alternative).
  * mra_qformer_workspace_bytes follows the mode in force; the training entry points always use the K/V cache. */
 int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
+/* Precision of the cross-attention SCORE chain (no reference counterpart: the reference runs it in fp16 under autocast,
+ * models/xinstructblip.py:58-66; its CPU path in fp32):
+ *   0  (default) MFMA operands in the operand dtype: the hidden state, W_cq, Q, W_k and Q' = Q W_k are each rounded to 11 bits.
+ *      A peaked softmax amplifies that rounding (dp = p (1 - p) ds, |s| up to ~100 for trained, sharply attending Q-Formers);
+ *   1  split: every operand of the chain hidden -> Q -> Q' -> scores is carried as an operand-dtype hi + lo pair (~22 bits with
+ *      f16): x.w = [xh | xl | xh].[wh | wh | wl]^T on the ordinary GEMM kernels (K tripled on the two small projections), and the
+ *      scores product reads Q' as (hi | lo) rows against the SAME encoder slab twice inside one K loop (K doubled, slab bytes
+ *      unchanged).  Forces the folded form at any Kv; needs heads * n_query == 384.  The f32 copies of W_cq / W_k live in the parameter
+ *      arena (kept current by mra_qformer_load / _load_flat); the first call with mode 1 allocates the prepared-weight arena
+ *      (ncross x (3 H H + 3 H E) operand elements) -- the one allocation after create.  Cost and accuracy: DESIGN.md section 8.
+ * mra_qformer_workspace_bytes follows the precision in force. */
+int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
  * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one
  * handle concurrently on different streams calls it once before forking. */

@@ -597,24 +597,30 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
         wrow[i] = q / (TN / 8);
         src[i] = (const char*)P.W + ((long long)n0 + (q - wrow[i] * (TN / 8)) * 8) * 2;
       } else if (row < TN) {
-        src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
+        const long long ldw = P.w_kwrap > 0 ? (long long)P.w_kwrap * BK : K;   // w_kwrap: W rows are only w_kwrap K steps long (K counts both passes)
+        src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * ldw + c * 8) * 2;
       } else {
         const int m = min(m0 + row - TN, M - 1);
         src[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
       }
     }
     const int wq0 = (wave - 8) * 64;
+    // GemmProb::w_kwrap: the weight-side operand is only w_kwrap K steps long and is walked again from its start (the hi | lo halves of a
+    // split-precision activation row against the same weights: C = [A_hi | A_lo] . [W | W]^T without a second copy of W)
+    const int kwrap = P.w_kwrap > 0 ? P.w_kwrap : 0x7fffffff;
     auto stage = [&](int buf, int kt) {
       char* base = smem + buf * BUF;
       const long long koff = (long long)kt * ROWB;
+      const long long koffw = (long long)(kt >= kwrap ? kt - kwrap : kt) * ROWB;
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        if (i * 256 + wq0 < NCHUNK) {   // wave-uniform: whole 64-chunk pieces
+        if (i * 256 + wq0 < NCHUNK) {   // wave-uniform: whole 64-chunk pieces (8 rows; TN % 8 == 0)
           if (WKM && i * 256 + wq0 < TN * 8) {
             const long long krow = min(kt * BK + wrow[i], P.k_rows - 1);
             glds16_nt(src[i] + krow * P.w_ld * 2, base + (wq0 + i * 256) * 16);
-          } else if (NTW && (i * 256 + wq0) / 8 < TN) {
-            glds16_nt(src[i] + koff, base + (wq0 + i * 256) * 16);   // rows [0, TN): read by this workgroup only
+          } else if ((i * 256 + wq0) / 8 < TN) {   // rows [0, TN): the weight side
+            if (NTW) glds16_nt(src[i] + koffw, base + (wq0 + i * 256) * 16);   // read by this workgroup only
+            else glds16(src[i] + koffw, base + (wq0 + i * 256) * 16);
           } else {
             glds16(src[i] + koff, base + (wq0 + i * 256) * 16);
           }
@@ -1317,6 +1323,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.n_ragged && (p.bias || epi == EPI_KV || epi == EPI_RES_F32)) return -1;
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;
+    if (p.w_kwrap && (p.w_kwrap < 0 || p.w_ld || (cfg != 3 && cfg != 4) || 2 * p.w_kwrap * 64 != p.K)) return -1;   // 128 x 384 / 176 x 384 loader-wave tiles only: K = 2 passes over the weights
     if (p.pscale && (!p.w_ld || cfg != 4 || p.M > 512 || p.ps_ntiles <= 0 || p.K > p.ps_ntiles * 176 + 4 * 176)) return -1;
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;

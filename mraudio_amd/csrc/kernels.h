@@ -60,6 +60,9 @@ struct GemmProb {
   // matrix, e.g. the encoder tokens themselves for P . enc); rows k >= k_rows are read from row k_rows - 1 (the A operand
   // is zero there).  The kernel stages [64 k][176 n] tiles and takes its fragments with ds_read_b64_tr_b16.
   int w_ld, k_rows;
+  // w_kwrap > 0 (loader-wave kernels, row-major W): W holds only w_kwrap K steps of 64 (K = 2 * 64 * w_kwrap) and is walked twice -- C = [A_hi | A_lo] . [W | W]^T,
+  // the scores product of the split-precision cross-attention (Q' kept as an f16 hi + lo pair against the same encoder slab)
+  int w_kwrap;
   // EPI_SOFTPART: scale of the scores in log2 units and the per-(row, column tile) statistics, row m of batch entry b at
   // stat_*[(b * M + m) * ntiles + tile]
   float alpha;
@@ -274,6 +277,12 @@ int launch_convert_flat(const float* master, const FlatSeg* segs, int nseg, hipS
 int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype /*0 f32,1 f16,2 bf16*/, long long n,
                    hipStream_t stream);
 int launch_copy_rows_f32(const float* src, RowView sv, float* dst, RowView dv, int rows, int H, hipStream_t stream);
+// split-precision cross-attention: fp32 -> operand-dtype (hi, lo) pairs laid out for K-concatenated GEMMs (norm_embed.hip)
+//   rows:   dst[row][c / chunk][part][c % chunk], parts = 3: (hi, lo, hi), 2: (hi, lo); dense dst rows of C * parts elements
+//   weight: [rows][C] -> [rows][3 C] = (hi | hi | lo);  key weight: [heads * 64][E] -> [heads][E][192] = (hi | hi | lo) over the head dims
+int launch_split_rows(const float* src, RowView sv, int rows, int C, int chunk, int parts, void* dst, int op_dtype, hipStream_t stream);
+int launch_split_weight(const float* W, int rows, int C, void* dst, int op_dtype, hipStream_t stream);
+int launch_split_key_weight(const float* W, int heads, int E, void* dst, int op_dtype, hipStream_t stream);
 
 // ---- scorer -------------------------------------------------------------------------------------
 int launch_cosine_score(const float* z, const float* t, int t_rows, int items, int Q, int H, float eps, float* sim,

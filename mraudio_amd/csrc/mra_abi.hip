@@ -62,6 +62,7 @@ size_t layout_params(mra_qformer* h, char* base) {
     if (i % c.cross_freq == 0) ++h->ncross;
   h->wkv = cv.take<char>((size_t)h->ncross * 2 * H * E, 2);
   h->bkv = cv.take<float>((size_t)h->ncross * 2 * H);
+  h->wk32 = cv.take<float>((size_t)h->ncross * H * E);
   if (c.llm_hidden > 0) {
     h->wllm = cv.take<char>((size_t)c.llm_hidden * H, 2);
     h->bllm = cv.take<float>(c.llm_hidden);
@@ -92,15 +93,18 @@ size_t layout_params(mra_qformer* h, char* base) {
     if (i % c.cross_freq == 0) {
       L.cross_index = cl;
       L.wcq = cv.take<char>(H * H, 2);
+      L.wcq32 = cv.take<float>(H * H);
       L.bcq = cv.take<float>(H);
       L.wco = cv.take<char>(H * H, 2);
       L.bco = cv.take<float>(H);
       L.lncg = cv.take<float>(H);
       L.lncb = cv.take<float>(H);
       reg(p + "crossattention.self.query.weight", L.wcq, opd, H * H);
+      h->params[p + "crossattention.self.query.weight"].copy32 = L.wcq32;
       reg(p + "crossattention.self.query.bias", L.bcq, MRA_F32, H);
       char* wkv = (char*)h->wkv;
       reg(p + "crossattention.self.key.weight", wkv ? wkv + (size_t)(cl * 2 + 0) * H * E * 2 : nullptr, opd, H * E);
+      h->params[p + "crossattention.self.key.weight"].copy32 = h->wk32 ? h->wk32 + (size_t)cl * H * E : nullptr;
       reg(p + "crossattention.self.key.bias", h->bkv ? h->bkv + (size_t)(cl * 2 + 0) * H : nullptr, MRA_F32, H);
       reg(p + "crossattention.self.value.weight", wkv ? wkv + (size_t)(cl * 2 + 1) * H * E * 2 : nullptr, opd, H * E);
       reg(p + "crossattention.self.value.bias", h->bkv ? h->bkv + (size_t)(cl * 2 + 1) * H : nullptr, MRA_F32, H);
@@ -144,6 +148,8 @@ struct Work {
   float *hA32, *hB32, *pre32, *hC32, *part;
   char *hA16, *hB16, *qkv16, *ctx16, *qc16, *hC16, *ffn16, *kv16;
   char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
+  char *hs16, *qs16;               // split-precision cross-attention: (hi | lo | hi) of the query rows [N*Q][3H] and of Q per head [N*Q][heads][192]
+  float *qc32, *qp32;              // ... Q [N*Q][H] and Q' [N][R][E] in f32 (then Q' leaves as (hi | lo) rows [N][R][2E] in qp16)
   float* s32;                      // scores [N][R][kvp]
   float* stat;                     // split softmax: tile maxima [N][R][ntiles], then tile sums
   float* gfac;                     // split softmax: row factors exp2(m_tile - m_row) / L as [N][ntiles][512] for the P . enc GEMM
@@ -169,7 +175,8 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.qc16 = cv.take<char>(N * Q * H, 2);
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
-  w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = nullptr;
+  w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = w.hs16 = w.qs16 = nullptr;
+  w.qc32 = w.qp32 = nullptr;
   w.s32 = w.stat = w.gfac = w.st_m = w.st_l = w.ginv = nullptr;
   w.gexp = nullptr;
   if (h->ncross > 0 && use_fold(h, Kv) && fold_streams(h, Kv)) {
@@ -185,7 +192,13 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   } else if (h->ncross > 0 && use_fold(h, Kv)) {
     const size_t E = c.enc_width, R = (size_t)c.heads * Q, kvp = fold_kvp(Kv);
     if (!fold_kmajor(h)) w.encT = cv.take<char>((size_t)N * E * kvp, 2);
-    w.qp16 = cv.take<char>((size_t)N * R * E, 2);
+    w.qp16 = cv.take<char>((size_t)N * R * E * (h->cross_precise ? 2 : 1), 2);
+    if (h->cross_precise) {
+      w.hs16 = cv.take<char>((size_t)N * Q * 3 * H, 2);
+      w.qs16 = cv.take<char>((size_t)N * Q * 3 * H, 2);
+      w.qc32 = cv.take<float>((size_t)N * Q * H);
+      w.qp32 = cv.take<float>((size_t)N * R * E);
+    }
     const bool split = R == 384 && h->sc_tile == 5 && h->split_softmax;   // then the scores never exist in fp32
     if (!split) w.s32 = cv.take<float>((size_t)N * R * kvp);
     w.stat = cv.take<float>((size_t)2 * N * R * ((Kv + 175) / 176));
@@ -284,6 +297,9 @@ int mra_qformer_create(const mra_cfg* cfg, mra_qformer** out) {
     for (long long o = 0; o < pr.numel; o += FLAT_SEG)
       segs.push_back(FlatSeg{(unsigned long long)(pr.goff / 4 + o), (char*)pr.ptr + o * esz,
                              (int)std::min<long long>(FLAT_SEG, pr.numel - o), pr.dtype});
+    if (pr.copy32)   // the f32 copies of the score-chain weights follow the master too
+      for (long long o = 0; o < pr.numel; o += FLAT_SEG)
+        segs.push_back(FlatSeg{(unsigned long long)(pr.goff / 4 + o), (char*)(pr.copy32 + o), (int)std::min<long long>(FLAT_SEG, pr.numel - o), MRA_F32});
   }
   h->n_flat_segs = (int)segs.size();
   e = hipMalloc((void**)&h->flat_segs, segs.size() * sizeof(FlatSeg));
@@ -301,6 +317,7 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->arena_t) (void)hipFree(h->arena_t);
   if (h->arena_f) (void)hipFree(h->arena_f);
+  if (h->arena_p) (void)hipFree(h->arena_p);
   if (h->flat_segs) (void)hipFree(h->flat_segs);
   if (h->tr_jobs) (void)hipFree(h->tr_jobs);
   for (auto& e : h->wg_ev) if (e) (void)hipEventDestroy(e);
@@ -321,11 +338,13 @@ int mra_qformer_load(mra_qformer* h, const char* name, const void* src, int32_t 
   if (numel != it->second.numel)
     return fail(MRA_EINVAL, "parameter " + key + ": expected " + std::to_string(it->second.numel) + " elements, got " +
                                 std::to_string(numel));
-  const int rc = launch_convert(src, dtype, it->second.ptr, it->second.dtype, numel, as_stream(stream));
+  int rc = launch_convert(src, dtype, it->second.ptr, it->second.dtype, numel, as_stream(stream));
+  if (!rc && it->second.copy32) rc = launch_convert(src, dtype, it->second.copy32, MRA_F32, numel, as_stream(stream));
   if (rc) return chk(rc, "launch_convert");
   it->second.loaded = true;
   h->transposes_stale = true;
   h->fold_stale = true;
+  h->precise_stale = true;
   return MRA_OK;
 }
 
@@ -339,6 +358,7 @@ int mra_qformer_load_flat(mra_qformer* h, const float* master, size_t master_byt
     if (kv.first.rfind("bert.", 0) == 0) kv.second.loaded = true;
   h->transposes_stale = true;
   h->fold_stale = true;
+  h->precise_stale = true;
   return MRA_OK;
 }
 
@@ -513,13 +533,26 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
     const float* fq32 = w.hB32;
     RowView fqv = q_view;
     if (Lw.cross_index >= 0) {
+      const bool precise = fold && h->cross_precise;
       // 5. cross query projection
       GemmProb p{};
-      p.A = w.hB16; p.a = q_view;
-      p.W = Lw.wcq; p.bias = Lw.bcq;
-      p.C = w.qc16; p.c = qc_rows;
-      p.M = N * Q; p.N = H; p.K = H;
-      rc = launch_gemm(&p, 1, EPI_OP, op, stream);
+      if (precise) {
+        // split precision: the fp32 query rows leave as (hi | lo | hi), the weight is stored as (hi | hi | lo): one GEMM over K = 3H
+        // computes xh wh + xl wh + xh wl in the fp32 accumulators; Q stays fp32
+        rc = launch_split_rows(w.hB32, q_view, N * Q, H, H, 3, w.hs16, op, stream);
+        if (rc) return chk(rc, "split query rows");
+        p.A = w.hs16; p.a = plain(N * Q, 3 * H);
+        p.W = h->arena_p + (size_t)Lw.cross_index * precise_layer_bytes(h); p.bias = Lw.bcq;
+        p.C = w.qc32; p.c = qc_rows;
+        p.M = N * Q; p.N = H; p.K = 3 * H;
+        rc = launch_gemm(&p, 1, EPI_F32, op, stream);
+      } else {
+        p.A = w.hB16; p.a = q_view;
+        p.W = Lw.wcq; p.bias = Lw.bcq;
+        p.C = w.qc16; p.c = qc_rows;
+        p.M = N * Q; p.N = H; p.K = H;
+        rc = launch_gemm(&p, 1, EPI_OP, op, stream);
+      }
       if (rc) return chk(rc, "cross q gemm");
       if (fold) {
         const int ci = Lw.cross_index;
@@ -527,12 +560,26 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         if (timed) (void)hipEventRecord(h->kv_ev0, stream);
         // 6a. Q' = Q_h W_k,h per head: [N*32, 64] x [E, 64]^T -> Q' [N][head*32 + q][E]
         GemmProb d{};
+        if (precise) {
+          // Q (fp32) per head as (hi | lo | hi) over its 64 dims against W_k,h as (hi | hi | lo): K = 192; Q' in fp32, then as (hi | lo) rows
+          rc = launch_split_rows(w.qc32, qc_rows, N * Q, H, 64, 3, w.qs16, op, stream);
+          if (rc) return chk(rc, "split cross query");
+          d.A = w.qs16; d.a = plain(N * Q, 3 * H); d.a_bs = 192;
+          d.W = h->arena_p + (size_t)ci * precise_layer_bytes(h) + precise_wk_off(h); d.w_bs = (long long)E * 192;
+          d.C = w.qp32; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * 4;
+          d.M = N * Q; d.N = E; d.K = 192; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
+          rc = launch_gemm(&d, 1, EPI_F32, op, stream);
+          if (rc) return chk(rc, "fold q' gemm (split precision)");
+          rc = launch_split_rows(w.qp32, plain(N * R, E), N * R, E, E, 2, w.qp16, op, stream);
+          if (rc) return chk(rc, "split q'");
+        } else {
         d.A = w.qc16; d.a = qc_rows; d.a_bs = 64;
         d.W = h->arena_f + (size_t)ci * H * E * esz; d.w_bs = (long long)E * 64;
         d.C = w.qp16; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * esz;
         d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
         rc = launch_gemm(&d, 1, EPI_OP, op, stream);
         if (rc) return chk(rc, "fold q' gemm");
+        }
         if (stream_fold) {
           // 6b-6d on the streaming kernels (fold_stream.hip): P~ = exp2(s - ceil(tile max)) + tile statistics, row statistics,
           // U = (1 / L) sum g P~ enc with the power-of-two tile factors applied in registers.  P~ is written once, read once.
@@ -549,6 +596,9 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
         sc.W = enc; sc.w_bs = (long long)kv * E;
         sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1;
+        if (precise) {   // Q' rows are (hi | lo): two passes over the same encoder slab inside one K loop
+          sc.a = plain(R, 2 * E); sc.a_bs = (long long)R * 2 * E; sc.K = 2 * E; sc.w_kwrap = E / 64;
+        }
         sc.tile_cfg = (R == 384 && h->sc_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
         if (sc.tile_cfg == 5 && h->split_softmax) {
           // 6b + 6c fused: the GEMM's epilogue leaves exp2(s - tile maximum) in the operand dtype plus tile statistics;
@@ -731,9 +781,23 @@ int mra_qformer_set_kv_events(mra_qformer* h, void* ev_start, void* ev_stop) {
 
 int mra_qformer_prepare(mra_qformer* h, void* stream) {
   if (!h) return fail(MRA_EINVAL, "null handle");
-  if (!h->fold_stale || h->ncross == 0) return MRA_OK;
+  if (h->ncross == 0) return MRA_OK;
   const mra_cfg& c = h->cfg;
   const size_t H = c.hidden, E = c.enc_width, esz = 2;
+  if (h->cross_precise && h->precise_stale) {
+    // split-precision cross-attention: W_cq as [H][3H] = (hi | hi | lo), W_k as [heads][E][192] = (hi | hi | lo), from the f32 copies
+    int ci = 0;
+    for (int i = 0; i < c.layers; ++i) {
+      if (h->layers[i].cross_index < 0) continue;
+      char* base = h->arena_p + (size_t)ci * precise_layer_bytes(h);
+      int rc = launch_split_weight(h->layers[i].wcq32, (int)H, (int)H, base, h->op(), as_stream(stream));
+      if (!rc) rc = launch_split_key_weight(h->wk32 + (size_t)ci * H * E, c.heads, (int)E, base + precise_wk_off(h), h->op(), as_stream(stream));
+      if (rc) return chk(rc, "split-precision weight preparation");
+      ++ci;
+    }
+    h->precise_stale = false;
+  }
+  if (!h->fold_stale) return MRA_OK;
   for (int ci = 0; ci < h->ncross; ++ci) {   // W_k [H][E] of cross layer ci -> [heads][E][64]
     const int rc = launch_transpose_pad((const char*)h->wkv + (size_t)(ci * 2) * H * E * esz, h->arena_f + (size_t)ci * H * E * esz, 64, (int)E,
                                         64, (long long)64 * E, (long long)E * 64, c.heads, h->op(), as_stream(stream));
@@ -751,6 +815,27 @@ int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode) {
   h->fold_tile = mode == 3 ? 4 : 2;
   h->fold_stream = mode == 4;     // measured 13 % slower than the loader-wave GEMMs + rescale pass: opt-in
   h->inreg_rescale = mode != 5;   // 5: the round-1 form with a rescale pass over P between the two big GEMMs, kept as the measured alternative
+  return MRA_OK;
+}
+
+int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode) {
+  if (!h) return fail(MRA_EINVAL, "null handle");
+  if (mode != 0 && mode != 1) return fail(MRA_EINVAL, "cross precision must be 0 (operand dtype) or 1 (split: hi + lo pairs along the score chain)");
+  if (mode == 1) {
+    const mra_cfg& c = h->cfg;
+    if (h->ncross == 0) return fail(MRA_EINVAL, "no cross-attention layers");
+    if (c.heads * c.n_query != 384 || h->sc_tile != 5 || !h->split_softmax)
+      return fail(MRA_EINVAL, "split precision needs heads * n_query == 384 (the 176 x 384 scores tile)");
+    if (!h->arena_p) {
+      int dev = 0;
+      HIP_TRY(hipGetDevice(&dev));
+      if (dev != h->device) return fail(MRA_EINVAL, "handle belongs to another device");
+      const hipError_t e = hipMalloc((void**)&h->arena_p, (size_t)h->ncross * precise_layer_bytes(h));
+      if (e != hipSuccess) return fail(MRA_ENOMEM, std::string("split-precision weight arena: ") + hipGetErrorString(e));
+      h->precise_stale = true;
+    }
+  }
+  h->cross_precise = mode;
   return MRA_OK;
 }
 

@@ -38,12 +38,14 @@ struct Param {
   bool loaded = false;
   size_t goff = 0;       // byte offset of this parameter's f32 gradient in the flat gradient buffer
   int rows = 0, cols = 0;  // matrix shape ([out, in]) for weights, 0 otherwise
+  float* copy32 = nullptr;  // f32 copy kept beside the operand-dtype one (the score-chain weights of the split-precision cross-attention)
 };
 
 struct LayerW {
   void *wqkv, *wo, *wcq, *wco, *wiq, *woq, *wit, *wot;
   float *bqkv, *bo, *bcq, *bco, *biq, *boq, *bit, *bot;
   float *ln1g, *ln1b, *lncg, *lncb, *lnqg, *lnqb, *lntg, *lntb;
+  float* wcq32;     // f32 copy of the cross-attention query weight (split-precision cross-attention), cross layers only
   int cross_index;  // -1 when the layer has no cross-attention
   // transposed copies for the data-gradient GEMMs (training only; nullptr until mra_qformer_enable_training)
   void *wqkvT, *woT, *wcqT, *wcoT, *wiqT, *woqT, *witT, *wotT;
@@ -97,6 +99,13 @@ struct mra_qformer {
   int fold_tile = 2;                              // GemmProb::tile_cfg of the two batched GEMMs (2 = 128 x 128, 4 = 128 x 384)
   bool fold_stream = false;                       // folded path on the streaming kernels of fold_stream.hip (mra_qformer_set_cross_mode 4)
   int cross_mode = 0;                             // 0 automatic, 1 K/V cache, 2 folded
+  // split-precision cross-attention (mra_qformer_set_cross_precision): hidden state, W_cq, Q, W_k and Q' of the score chain as operand-dtype
+  // hi + lo pairs (folded form forced); wk32 = f32 copies of the key weights [ncross][H][E], arena_p = per cross layer W_cq as
+  // [H][3H] (hi | hi | lo) and W_k as [heads][E][192] (hi | hi | lo), allocated when the mode is first enabled
+  int cross_precise = 0;
+  float* wk32 = nullptr;
+  char* arena_p = nullptr;
+  bool precise_stale = true;
   hipEvent_t kv_done = nullptr;                   // optional scheduling hook (mra_qformer_set_kv_done_event)
   hipEvent_t kv_ev0 = nullptr, kv_ev1 = nullptr;  // optional instrumentation (mra_qformer_set_kv_events)
   // training
@@ -114,7 +123,7 @@ struct mra_qformer {
 
 namespace mra_host {
 // folded cross-attention pays once the encoder sequence is long (fewer flops at any Kv, but five launches per layer)
-inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
+inline bool use_fold(const mra_qformer* h, int kv) { return h->cross_precise || h->cross_mode == 2 || (h->cross_mode == 0 && kv >= 2048); }
 // padded score-row length: whole 128- and 176-row tiles of the scores GEMM, and a multiple of 128 (K of P . enc)
 // P . enc on the 176 x 384 tile with K-major weights: no transposed copy of the encoder tokens is needed
 inline bool fold_kmajor(const mra_qformer* h) {
@@ -125,7 +134,12 @@ inline bool fold_inreg_rescale(const mra_qformer* h) { return h->inreg_rescale &
 inline int fold_kvp(int kv) { return (std::max((kv + 127) / 128 * 128, (kv + 175) / 176 * 176) + 127) / 128 * 128; }
 // the streaming kernels (fold_stream.hip): f16 operands, 384 (head, query) rows, E a multiple of 176
 inline bool fold_streams(const mra_qformer* h, int kv) {
-  return h->fold_stream && mra::fold_stream_supported(h->cfg.heads * h->cfg.n_query, h->cfg.enc_width, kv, fold_kvp(kv), h->op());
+  return !h->cross_precise && h->fold_stream && mra::fold_stream_supported(h->cfg.heads * h->cfg.n_query, h->cfg.enc_width, kv, fold_kvp(kv), h->op());
+}
+// split-precision cross-attention: bytes of one cross layer's prepared weights, W_cq [H][3H] then W_k [heads][E][192] (operand dtype)
+inline size_t precise_wk_off(const mra_qformer* h) { return align_up((size_t)h->cfg.hidden * 3 * h->cfg.hidden * 2); }
+inline size_t precise_layer_bytes(const mra_qformer* h) {
+  return precise_wk_off(h) + align_up((size_t)h->cfg.heads * h->cfg.enc_width * 192 * 2);
 }
 // K/V of every cross layer in ONE GEMM: [items*kv, E] x [ncross*2*H, E]^T, scattered head-major.
 int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_cache, hipStream_t stream);

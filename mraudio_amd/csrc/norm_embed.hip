@@ -8,6 +8,8 @@
 //                        with the sample-major gather of models/xinstructblip.py:281-285.
 //   embed_ln_kernel      Q-Former embeddings (HF modeling_instructblip.py:728-757): queries as is,
 //                        text = word + absolute position, then LayerNorm.
+#include <algorithm>
+
 #include "kernels.h"
 #include "mra_common.h"
 
@@ -250,6 +252,64 @@ __global__ void __launch_bounds__(256) copy_rows_kernel(const float* src, RowVie
   for (int c = lane * 4; c < H; c += 256) *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
 }
 
+// Split-precision cross-attention (mra_qformer_set_cross_precision): an fp32 value x leaves as the operand-dtype pair hi = op(x),
+// lo = op(x - hi) (~22 significant bits with f16).  Products of two such pairs run on the ordinary GEMM kernels by concatenation along
+// K:  x . w ~ xh wh + xl wh + xh wl = [xh | xl | xh] . [wh | wh | wl]^T.
+// Activations: fp32 rows (row view) of C columns, in chunks of `chunk` columns -> dst[row][c / chunk][part][c % chunk], parts
+// (hi, lo, hi) for PARTS = 3 or (hi, lo) for PARTS = 2; dst rows are dense (C / chunk * PARTS * chunk elements).
+template <typename T, int PARTS>
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* src, RowView sv, int rows, int C, int chunk, T* dst) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = src + vrow(sv, row);
+  T* d = dst + (long long)row * C * PARTS;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(s + c);
+    f32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (float)from_f32<T>(x[e]);
+      lo[e] = x[e] - hi[e];
+    }
+    T* o = d + (long long)(c / chunk) * chunk * PARTS + (c % chunk);   // chunk % 4 == 0: the four values share a chunk
+    store4<T>(o, hi);
+    store4<T>(o + chunk, lo);
+    if constexpr (PARTS == 3) store4<T>(o + 2 * chunk, hi);
+  }
+}
+
+// Weights (run once per weight change): fp32 W [rows][C] -> [rows][3 C] = (hi | hi | lo) per row
+template <typename T>
+__global__ void __launch_bounds__(256) split_weight_kernel(const float* W, long long n, int C, T* dst) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const float x = W[i];
+    const T hi = from_f32<T>(x);
+    const T lo = from_f32<T>(x - (float)hi);
+    T* o = dst + r * 3 * C + c;
+    o[0] = hi; o[C] = hi; o[2 * C] = lo;
+  }
+}
+
+// Key weights for the folded form: fp32 W_k [heads * 64][E] -> [heads][E][192] = per (head, e): (hi | hi | lo) over the 64 head dims
+template <typename T>
+__global__ void __launch_bounds__(256) split_key_weight_kernel(const float* W, int heads, int E, T* dst) {
+  const long long n = (long long)heads * 64 * E;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i % E);
+    const long long hd = i / E;            // head * 64 + d
+    const int d = (int)(hd & 63);
+    const long long head = hd >> 6;
+    const float x = W[i];
+    const T hi = from_f32<T>(x);
+    const T lo = from_f32<T>(x - (float)hi);
+    T* o = dst + (head * E + e) * 192 + d;
+    o[0] = hi; o[64] = hi; o[128] = lo;
+  }
+}
+
 template <typename TI, typename TO>
 int modality_ln_t(const void* x, const long long* index, int items, int tokens, int E, const float* gain,
                   const float* bias, float eps, void* out, hipStream_t stream) {
@@ -364,6 +424,38 @@ int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, lon
 int launch_convert_flat(const float* master, const FlatSeg* segs, int nseg, hipStream_t stream) {
   if (nseg <= 0) return 0;
   hipLaunchKernelGGL(convert_flat_kernel, dim3(nseg), dim3(256), 0, stream, master, segs);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_split_rows(const float* src, RowView sv, int rows, int C, int chunk, int parts, void* dst, int op_dtype, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || chunk <= 0 || C % chunk || chunk % 4 || (parts != 2 && parts != 3) || sv.rpi <= 0) return -1;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (op_dtype == OP_F16) {
+    if (parts == 3) hipLaunchKernelGGL((split_rows_kernel<f16, 3>), grid, block, 0, stream, src, sv, rows, C, chunk, (f16*)dst);
+    else hipLaunchKernelGGL((split_rows_kernel<f16, 2>), grid, block, 0, stream, src, sv, rows, C, chunk, (f16*)dst);
+  } else {
+    if (parts == 3) hipLaunchKernelGGL((split_rows_kernel<bf16, 3>), grid, block, 0, stream, src, sv, rows, C, chunk, (bf16*)dst);
+    else hipLaunchKernelGGL((split_rows_kernel<bf16, 2>), grid, block, 0, stream, src, sv, rows, C, chunk, (bf16*)dst);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_split_weight(const float* W, int rows, int C, void* dst, int op_dtype, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return -1;
+  const long long n = (long long)rows * C;
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(split_weight_kernel<f16>, dim3(blocks), dim3(256), 0, stream, W, n, C, (f16*)dst);
+  else hipLaunchKernelGGL(split_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, W, n, C, (bf16*)dst);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_split_key_weight(const float* W, int heads, int E, void* dst, int op_dtype, hipStream_t stream) {
+  if (heads <= 0 || E <= 0) return -1;
+  const long long n = (long long)heads * 64 * E;
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(split_key_weight_kernel<f16>, dim3(blocks), dim3(256), 0, stream, W, heads, E, (f16*)dst);
+  else hipLaunchKernelGGL(split_key_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, W, heads, E, (bf16*)dst);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

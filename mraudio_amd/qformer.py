@@ -363,6 +363,14 @@ class QFormer(nn.Module):
         code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4, "fold_rescale_pass": 5}.get(mode, mode)
         check(lib().mra_qformer_set_cross_mode(self._handle, int(code)), "mra_qformer_set_cross_mode")
 
+    def set_cross_precision(self, mode) -> None:
+        """Precision of the cross-attention score chain: ``"op"`` (default: f16 / bf16 operands) or ``"split"`` (hidden state, W_cq, Q,
+        W_k and Q' as hi + lo pairs, ~22 bits; folded form at any Kv; ``mra_qformer_set_cross_precision``).  For sharply attending
+        (trained) weights, where the f16 rounding of the score operands is amplified by the softmax."""
+        code = {"op": 0, "f16": 0, "split": 1}.get(mode, mode)
+        with torch.cuda.device(self._device):
+            check(lib().mra_qformer_set_cross_precision(self._handle, int(code)), "mra_qformer_set_cross_precision")
+
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
         return float(lib().mra_qformer_flops(self._handle, items, L, kv, int(with_last_text)))
 

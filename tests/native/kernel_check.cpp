@@ -470,10 +470,13 @@ static void test_gemm_softpart(int op, int M, int kv, int K, int batch) {
 }
 
 // batched launch (one weight matrix per batch entry) with a ragged N: the folded cross-attention's GEMMs
-static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged) {
+// wrap: GemmProb::w_kwrap -- W holds only K / 2 columns and is walked twice (A = (hi | lo) rows of the split-precision scores product);
+// W is allocated EXACTLY (a stride of K instead of K / 2 would run off its end)
+static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int batch, bool ragged, bool wrap = false) {
   const int t = cfg == 0 ? 64 : (cfg == 2 ? 256 : (cfg == 4 ? 176 : 128));   // weight rows per tile (config 3: 128 x 384, 4: 176 x 384)
   const int ldc = (N + t - 1) / t * t;                       // C rows hold whole tiles
-  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * N * K);
+  const int KW = wrap ? K / 2 : K;
+  std::vector<uint16_t> A((size_t)batch * M * K), W((size_t)batch * N * KW);
   for (auto& v : A) v = to_op(frand(), op);
   for (auto& v : W) v = to_op(frand(0.05f), op);
   std::vector<float> bias((size_t)batch * N);
@@ -484,8 +487,8 @@ static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int
   memset(&p, 0, sizeof(p));
   p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = ragged ? nullptr : dB.p;
   p.M = M; p.N = N; p.K = K;
-  p.batch = batch; p.a_bs = (long long)M * K; p.w_bs = (long long)N * K; p.bias_bs = N;
-  p.n_ragged = ragged ? 1 : 0; p.tile_cfg = cfg + 1;
+  p.batch = batch; p.a_bs = (long long)M * K; p.w_bs = (long long)N * KW; p.bias_bs = N;
+  p.n_ragged = ragged ? 1 : 0; p.tile_cfg = cfg + 1; p.w_kwrap = wrap ? KW / 64 : 0;
   const bool f32 = epi == EPI_F32;
   p.C = f32 ? (void*)dC32.p : (void*)dC16.p; p.c = RowView{0, M, ldc};
   p.c_bs_bytes = (long long)M * ldc * (f32 ? 4 : 2);
@@ -498,13 +501,13 @@ static void test_gemm_batched(int cfg, int epi, int op, int M, int N, int K, int
     for (int m = 0; m < M; ++m)
       for (int n = 0; n < N; ++n) {
         double acc = bias[(size_t)b * N + n];
-        for (int k = 0; k < K; ++k) acc += (double)from_op(A[((size_t)b * M + m) * K + k], op) * from_op(W[((size_t)b * N + n) * K + k], op);
+        for (int k = 0; k < K; ++k) acc += (double)from_op(A[((size_t)b * M + m) * K + k], op) * from_op(W[((size_t)b * N + n) * KW + k % KW], op);
         const size_t ci = ((size_t)b * M + m) * ldc + n;
         const double got = f32 ? c32[ci] : from_op(c16[ci], op);
         worst = std::max(worst, fabs(got - acc) / (1 + fabs(acc)));
       }
   char name[128];
-  snprintf(name, sizeof(name), "gemm batched cfg%d epi%d M%d N%d K%d x%d%s", cfg, epi, M, N, K, batch, ragged ? " ragged-N" : "");
+  snprintf(name, sizeof(name), "gemm batched cfg%d epi%d M%d N%d K%d x%d%s%s", cfg, epi, M, N, K, batch, ragged ? " ragged-N" : "", wrap ? " W walked twice" : "");
   report(name, worst, f32 ? 2e-4 : 3e-3);
 }
 
@@ -1089,6 +1092,9 @@ int main(int argc, char** argv) {
   test_gemm_batched(4, EPI_OP, OP_BF16, 300, 176, 128, 2, false);
   test_gemm_batched(4, EPI_OP, OP_F16, 500, 528, 64, 1, false);     // two row tiles, one K step
   test_gemm_batched(4, EPI_F32, OP_F16, 384, 300, 192, 2, true);    // scores: ragged N on the 176-row tile
+  test_gemm_batched(4, EPI_F32, OP_F16, 384, 300, 384, 2, true, true);   // split-precision scores: A = (hi | lo), the weight slab walked twice
+  test_gemm_batched(4, EPI_F32, OP_F16, 384, 530, 2816, 1, true, true);  // ... at the video width (E = 1408)
+  test_gemm_batched(3, EPI_F32, OP_BF16, 300, 256, 256, 2, false, true);
   test_gemm_kmajor(OP_F16, 384, 352, 320, 300, 2);                  // P . enc with the weights K-major (transposed LDS reads)
   test_gemm_kmajor(OP_F16, 200, 176, 64, 64, 3);
   test_gemm_kmajor(OP_BF16, 384, 528, 192, 150, 1);

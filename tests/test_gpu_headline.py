@@ -132,12 +132,31 @@ def _cross_probabilities(w, cfg, collect, enc, layer):
     return torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
 
 
-@pytest.mark.parametrize("kv,gain", [(2100, 4.0), (300, 4.0), (2100, 7.0)])
-def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
-    """Trained Q-Formers attend sharply; N(0, 0.02) weights never do (p ~ 1/Kv everywhere).  Here most probability rows
-    have a maximum > 0.5 and the bulk of their entries below the f16 normal range -- the regime where a normalised f16 P
-    would lose mass.  Kv = 2100 runs 12 column tiles of the split softmax (automatic fold), Kv = 300 forces it on 2 tiles;
-    both modes must meet the usual bars against the oracle."""
+# Peaked attention: what the f16 score chain delivers and what the split-precision chain (``set_cross_precision("split")``) buys.
+# Measured on MI355X (gpurun_out/r03b/peaked.log; the CPU emulation of every rounding point, tests/study_peaked_precision.py,
+# predicts the same numbers within 30 %), worst of the four f16 formulations | split:
+#   (Kv, gain)   row max   |dz|              logits            similarities
+#   2100, 4      0.6       1.4e-2 | 7.0e-3   7.3e-4 | 4.4e-4   1.3e-3 | 7.2e-4
+#    300, 4      0.6       1.7e-2 | 6.8e-3   3.3e-4 | 2.1e-4   1.6e-3 | 7.7e-4
+#    300, 5      0.8       4.5e-2 | 1.5e-2   3.0e-3 | 3.0e-4   4.3e-3 | 9.3e-4
+#   2100, 5      0.8       5.1e-2 | 1.9e-2   1.3e-3 | 2.5e-4   4.4e-3 | 1.2e-3
+#   2100, 7      0.98      4.3e-1 | 1.8e-1   2.7e-3 | 4.9e-4   4.5e-2 | 6.8e-3
+# STRICT = the north star's bars, unwidened: |dz| < 1e-2, similarity logits AND per-query similarities within 1e-3.
+# Boundary (tested below): the f16 chain holds the logit bar up to gain 4; the split chain holds ALL strict bars at gain 4 and the
+# logit bar at every gain including near-one-hot rows; beyond gain 4 the hidden states / per-query similarities exceed the strict
+# bars in either chain, because what is left is the f16 operand rounding of the REST of the network (~1e-3 of the hidden state entering
+# each cross layer), which the softmax amplifies by p (1 - p) |s|: only fp32-grade arithmetic everywhere would remove it.
+PEAKED_CASES = [(2100, 4.0), (300, 4.0), (300, 5.0), (2100, 5.0), (2100, 7.0)]
+_PEAKED_CACHE = {}
+
+
+def _strict(r):
+    return r["dz"] < Z_ATOL and r["dlogit"] <= LOGIT_RTOL and r["dsim"] <= LOGIT_RTOL
+
+
+def _peaked_report(dev, kv, gain):
+    if (kv, gain) in _PEAKED_CACHE:
+        return _PEAKED_CACHE[(kv, gain)]
     from mraudio_amd.qformer import QFormer, QFormerConfig
 
     cfg = QFormerConfig(enc_width=1408)
@@ -165,8 +184,9 @@ def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
     t = h[:, 32]
     sim_ref, logit_ref = O.cosine_scores(h[:, :32], t)
     report = {}
-    for mode in ("fold", "fold_rescale_pass", "fold_stream", "kv_cache"):
-        qf.set_cross_mode(mode)
+    for mode in ("fold", "fold_rescale_pass", "fold_stream", "kv_cache", "split"):
+        qf.set_cross_precision("split" if mode == "split" else "op")
+        qf.set_cross_mode("auto" if mode == "split" else mode)
         res = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True, want_cls=True)
         z, cls = res["query"].cpu(), res["cls"].cpu()
         assert torch.isfinite(z).all()
@@ -175,22 +195,57 @@ def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
                             dlogit=(logit - logit_ref).abs().max().item() / logit_ref.abs().max().item(),
                             dsim=(sim - sim_ref).abs().max().item() / sim_ref.abs().max().item())
     qf.set_cross_mode("auto")
-    print("peaked", kv, gain, report)
-    # What bounds accuracy here is the f16 rounding of the attention operands (the reference's own autocast dtype), which a
-    # peaked softmax amplifies: dp = p (1 - p) ds with |s| up to ~40.  Measured on MI355X (r02b): at gain 4 both formulations
-    # land at rel 2.0e-3 / logits 2.4e-4 .. 3.9e-4 -- the K/V-cache path, whose softmax statistics never leave fp32, is no
-    # better than the split softmax; at gain 7 (rows ~one-hot, near-ties between keys decided by the last f16 bit) both sit
-    # at rel 2.8e-2.  So: the north star's 1e-3 on the similarity logits where f16 operands can deliver it (gain 4), a
-    # 3x hidden-state bar there, and everywhere "the split softmax costs nothing against the fp32-statistics path".
+    qf.set_cross_precision("op")
+    print("peaked", kv, gain, {m: {k: float(f"{v:.2e}") for k, v in r.items()} for m, r in report.items()})
+    _PEAKED_CACHE[(kv, gain)] = report
+    return report
+
+
+@pytest.mark.parametrize("kv,gain", PEAKED_CASES)
+def test_peaked_attention_through_the_split_softmax(dev, kv, gain):
+    """Trained Q-Formers attend sharply; N(0, 0.02) weights never do (p ~ 1/Kv everywhere).  Here most probability rows
+    have a maximum > 0.5 and the bulk of their entries below the f16 normal range -- the regime where a normalised f16 P
+    would lose mass.  Kv = 2100 runs 12 column tiles of the split softmax (automatic fold), Kv = 300 forces it on 2 tiles.
+    What bounds accuracy is NOT the split softmax (the K/V-cache path, whose statistics never leave fp32, is no better) but the f16
+    rounding of the score-chain operands, which the softmax amplifies: dp = p (1 - p) ds with |s| ~ 40 .. 120.  These are the
+    REGRESSION GUARDS of the f16 chain (measured values x ~1.5, table above) -- the north star's own bars are asserted in the
+    three tests below.  Every split-softmax form must be no worse than the fp32-statistics path, the split-precision chain
+    better than the f16 chain."""
+    report = _peaked_report(dev, kv, gain)
+    guard = {4.0: dict(dz=3 * Z_ATOL, rel=4e-3, dlogit=LOGIT_RTOL, dsim=2.5 * LOGIT_RTOL),
+             5.0: dict(dz=8e-2, rel=8e-3, dlogit=5e-3, dsim=7e-3),
+             7.0: dict(dz=7e-1, rel=6e-2, dlogit=5e-3, dsim=8e-2)}[gain]
     for mode, r in report.items():
-        if gain <= 4.0:
-            assert r["dz"] < 3 * Z_ATOL and r["rel"] < 4e-3, (mode, kv, gain, r)
-            assert r["dlogit"] <= LOGIT_RTOL and r["dsim"] <= 2 * LOGIT_RTOL, (mode, kv, gain, r)
-        else:
-            assert r["rel"] < 6e-2, (mode, kv, gain, r)
+        for k, bar in guard.items():
+            assert r[k] <= bar, (mode, kv, gain, k, r)
     for mode in ("fold", "fold_rescale_pass", "fold_stream"):   # the split-softmax forms: row factors inside P.enc / rescale pass / power-of-two factors
         assert report[mode]["rel"] < 1.25 * report["kv_cache"]["rel"] + 5e-4, report
         assert report[mode]["dlogit"] < 1.5 * report["kv_cache"]["dlogit"] + 5e-4, report
+    assert report["split"]["rel"] < 0.75 * report["fold"]["rel"], report
+
+
+@pytest.mark.parametrize("kv,gain", [(2100, 4.0), (300, 4.0)])
+def test_split_precision_meets_the_unwidened_bars_on_peaked_attention(dev, kv, gain):
+    """the ORIGINAL assertions (|dz| < 1e-2, logits and similarities within 1e-3), unwidened, at gain 4 (median row
+    maximum 0.6) -- met by the split-precision score chain (the f16 chain lands at 1.2e-2 .. 1.7e-2 / 1.3e-3 .. 1.6e-3 there)."""
+    r = _peaked_report(dev, kv, gain)["split"]
+    assert _strict(r), (kv, gain, r)
+
+
+@pytest.mark.parametrize("kv,gain", PEAKED_CASES)
+def test_split_precision_keeps_the_logit_bar_at_every_gain(dev, kv, gain):
+    """The north star's own quantity -- similarity logits within 1e-3 relative -- holds with the split-precision chain up to
+    near-one-hot rows (gain 7, row maximum 0.98: 4.9e-4 measured; the f16 chain: 0.7e-3 .. 2.7e-3 depending on the formulation)."""
+    r = _peaked_report(dev, kv, gain)["split"]
+    assert r["dlogit"] <= LOGIT_RTOL, (kv, gain, r)
+
+
+@pytest.mark.xfail(strict=True, reason="tested boundary: beyond gain 4 the hidden-state / per-query-similarity bars are out of reach of f16 "
+                   "operands anywhere in the network (measured table above); a pass here means the boundary moved -- update README / DESIGN")
+@pytest.mark.parametrize("kv,gain,mode", [(300, 5.0, "fold"), (2100, 5.0, "kv_cache"), (2100, 5.0, "split"), (2100, 7.0, "fold"), (2100, 7.0, "split")])
+def test_strict_bars_beyond_gain_4_are_out_of_reach(dev, kv, gain, mode):
+    r = _peaked_report(dev, kv, gain)[mode]
+    assert _strict(r), (kv, gain, mode, r)
 
 
 def test_one_hot_attention_row(dev):
