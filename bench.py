@@ -69,6 +69,7 @@ def parse():
                     help="cross-attention formulation (auto = folded from Kv >= 2048; fold_stream / fold384: A/B variants)")
     ap.add_argument("--cross-precision", default="op", choices=["op", "split"],
                     help="precision of the cross-attention score chain: op = f16 / bf16 operands (default); split = hi + lo pairs (~22 bits) for sharply attending weights")
+    ap.add_argument("--chain-ring", type=int, default=-1, help="A/B: mask of chain GEMMs on the ring kernel's tiles (1 QKV, 2 FFN-up, 4 residual projections; -1 = library default)")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed ViT-g encode stage")
@@ -114,6 +115,8 @@ def main():
         getattr(model, f"{m}_Qformer").set_cross_mode(args.cross_mode)
         if args.cross_precision != "op":
             getattr(model, f"{m}_Qformer").set_cross_precision(args.cross_precision)
+        if args.chain_ring >= 0:
+            getattr(model, f"{m}_Qformer").set_option("chain_ring", args.chain_ring)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = {m: torch.randn(n_local, kv[m], ENC_WIDTH[m], generator=g, device=dev, dtype=torch.float16) for m in ("video", "audio")}
     ids = torch.randint(1000, 30000, (n_local, L), generator=g, device=dev)

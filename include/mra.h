@@ -159,6 +159,10 @@ int mra_qformer_set_cross_mode(mra_qformer* h, int32_t mode);
  *      (ncross x (3 H H + 3 H E) operand elements) -- the one allocation after create.  Cost and accuracy: DESIGN.md section 8.
  * mra_qformer_workspace_bytes follows the precision in force. */
 int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode);
+/* Per-handle tuning options (no reference counterpart; results are the same to fp32 summation order).
+ *   "chain_ring"  mask: which GEMMs of the 12-layer chain run on the ring kernel's exact-fit tiles when the launch has ~1 k rows or more:
+ *                 bit 0 QKV (144 x 128), bit 1 FFN-up (192 x 128), bit 2 the residual projections (96 x 64); default 7 (all).  DESIGN.md section 8. */
+int mra_qformer_set_option(mra_qformer* h, const char* name, int32_t value);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
  * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one
  * handle concurrently on different streams calls it once before forking. */

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "mra_qformer_set_kv_done_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mra_qformer_set_cross_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "mra_qformer_set_cross_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mra_qformer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "mra_qformer_prepare": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mra_kv_cache_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "mra_kv_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

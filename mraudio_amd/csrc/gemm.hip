@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <utility>
 
 #include "kernels.h"
@@ -360,7 +361,7 @@ __device__ __forceinline__ void epilogue_softpart(const GemmProb& P, f32x4 (&acc
 // kernels' 168-register budget, 300-350 in the eight-phase kernel).
 template <typename T, int TN, int TM, int FN, int FM, int NT, int EPI, bool BIAS_FIRST = false>
 __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[FN][FM], char* smem, int n0, int m0, int wn0,
-                                               int wm0, int tid) {
+                                               int wm0, int tid, bool stages = true) {   // stages == false (wave-uniform): this wave owns no accumulators, it only helps copying out
   const int lane = tid & 63;
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   f32x4 bias4[BIAS_FIRST ? FN : 1];
@@ -375,6 +376,7 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
       }
     }
   }
+  if (stages)
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int nl = wn0 + i * 16 + ln;
@@ -999,6 +1001,232 @@ __global__ void __launch_bounds__(512) gemm_p8_mixed_kernel(const GemmArgs args)
 }
 
 // =================================================================================================
+// ring: one workgroup per CU on an exact-fit tile, K tiles through a ring of STAGES LDS slots, two wave groups on alternating K tiles
+// =================================================================================================
+// At ~2 k activation rows a launch is ONE round of the chip: its time is the time of its slowest CU, and with a single workgroup on a
+// CU nothing overlaps by occupancy.  Stamped timelines (tests/native/gemm_bench stamp; QKV 2048 x 768 -> 2304) of the forms tried:
+//   two-buffer loop, 288 tiles of 128 x 128                                   17.6 us per launch
+//   ring, all waves stage / read / multiply in lockstep (6 waves, 3 in flight) 16.0 us: per 64-deep step DMA issue ~400 + fragment reads
+//                                                                              ~650 + MFMAs ~770 cycles in series
+//   two groups by K parity, one group staging, L2 "touch" warm-up of the tile  19.1 us: touches 1.3-2.9 us (64 lines per wave instruction
+//                                                                              serialise on the CU's address path; no gain behind them),
+//                                                                              first data at 4.5 us, 0.54 us per interval, group reduction
+//                                                                              1.2 us, direct 8-byte epilogue stores by four waves 3.4 us
+// What is kept:
+//   * tile shapes that give EXACTLY one workgroup per CU at the chain's shapes (QKV 2048 x 2304 = 16 x 16 tiles of 128 rows x 144 weight
+//     rows; FFN-up 2 x 1024 x 3072 = 2 x 8 x 16 tiles of 128 x 192; the N = 768 projections 64 rows x 96 weight rows): half the operand
+//     bytes per CU of 64 x 64 tiles;
+//   * 2 x NWC waves = two groups that each own the WHOLE tile for every other K tile (wave w and wave w + NWC share a SIMD).  One barrier
+//     per K tile opens an interval in which one group reads the tile's fragments from LDS into registers while its SIMD partners run
+//     the MFMAs of the previous tile; every wave stages its share of the tile STAGES - 2 ahead (counted vmcnt: STAGES - 3 tiles stay in
+//     flight across the barrier), the readers behind their reads, the multipliers behind their MFMAs;
+//   * epilogue: group 1's partial sums go to group 0 through the ring's space; group 0 finishes the values (bias, GELU) and lays the tile
+//     out row-major in LDS; ALL waves copy it out in 16-byte pieces of whole rows (fp32 outputs too; the fp32 residual was loaded into
+//     the accumulators before the K loop).
+// Slot of tile t: t % STAGES; it is re-staged in interval t + 2, after its readers passed the barrier that follows their MFMAs' operand wait.
+template <int N>
+__device__ __forceinline__ void ring_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int TN, int TM, int WGN, int WGM, int STAGES, int EPI>
+__global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const GemmArgs args) {
+  constexpr int BK = 64, ROWB = BK * 2;
+  constexpr int NWC = WGN * WGM, NW = 2 * NWC, NT = NW * 64;
+  constexpr int WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
+  constexpr int ROWS = TN + TM, NPIECE = ROWS / 8, PPW = (NPIECE + NW - 1) / NW;   // 1 KiB pieces per K tile / per wave (upper bound)
+  constexpr int BUF = ROWS * ROWB;
+  constexpr bool F32OUT = EPI == EPI_RES_F32 || EPI == EPI_F32;
+  constexpr int OSZ = F32OUT ? 4 : 2, PITCH = TN * OSZ + 16;                         // staged output tile: row-major, padded rows
+  constexpr int RED_BYTES = NWC * FN * FM * 1024;
+  static_assert(TN % (16 * WGN) == 0 && TM % (16 * WGM) == 0 && ROWS % 8 == 0 && TN % 8 == 0, "tile must split over the waves; whole pieces");
+  static_assert(STAGES >= 4 && (STAGES - 3) * PPW <= 63, "vmcnt holds 6 bits");
+  static_assert(RED_BYTES + TM * PITCH <= STAGES * BUF, "reduction + staged tile reuse the ring");
+  static_assert(EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_RES_F32 || EPI == EPI_F32, "epilogues of the ring kernel");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave / NWC, gw = wave - group * NWC;
+  const int wn0 = (gw / WGM) * WTN;
+  const int wm0 = (gw % WGM) * WTM;
+  int n0, m0;
+  const GemmProb& P = pick_tile<TN, TM>(args, n0, m0);
+  const int K = P.K, M = P.M;
+  const int nk = K / BK;
+#ifdef MRA_GEMM_EXPERIMENTS
+  // stamped timeline (gemm_bench stamp): per workgroup and wave 8 x u64 of wall clock (100 MHz) / shader clock at the phase boundaries
+  unsigned long long* stamp = args.dbg ? args.dbg + ((size_t)blockIdx.x * NW + wave) * 16 : nullptr;
+#define RING_STAMP(i) do { if (stamp && lane == 0) { stamp[i] = wall_clock64(); stamp[8 + i] = clock64(); } } while (0)
+#else
+#define RING_STAMP(i) do { } while (0)
+#endif
+  RING_STAMP(0);
+
+  // this wave's pieces of every K tile: p = wave + i * NW; piece p = LDS rows 8 p .. 8 p + 7 (rows [0, TN) weights, then activations)
+  const char* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = min(wave + i * NW, NPIECE - 1);
+    const int row = p * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < TN) {   // wave-uniform: TN % 8 == 0
+      src[i] = (const char*)P.W + ((long long)min(n0 + row, P.N - 1) * K + c * 8) * 2;
+    } else {
+      const int m = min(m0 + row - TN, M - 1);  // rows past M are computed on a clamped row and never stored
+      src[i] = (const char*)P.A + (view_off(P.a, m) + c * 8) * 2;
+    }
+  }
+  const bool full = wave + (PPW - 1) * NW < NPIECE;   // this wave issues PPW pieces per K tile (else PPW - 1)
+  auto stage = [&](int slot, int kt) {
+    char* base = smem + slot * BUF + wave * 1024;
+    const long long koff = (long long)kt * ROWB;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      if (i + 1 < PPW || full) glds16(src[i] + koff, base + i * (NW * 1024));
+  };
+  // the first STAGES - 2 tiles go out before anything else is computed
+#pragma unroll
+  for (int t = 0; t < STAGES - 2; ++t)
+    if (t < nk) stage(t, t);
+  RING_STAMP(1);
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int r = lane & 15;
+    const int c = (4 * ks + (lane >> 4)) ^ ((r >> 1) & 7);
+    foff[ks] = r * ROWB + c * 16;
+  }
+  f32x4 acc[FN][FM];
+  if (EPI == EPI_RES_F32 && group == 0) {
+    // ordinary loads behind the prologue's DMA: the bias add below makes the compiler wait for them with vmcnt(0), which also covers the
+    // prologue's tiles (one round trip for both); nothing of them stays in the queue the loop counts
+    accumulators_from_residual<FN, FM>(P, acc, n0 + wn0, m0 + wm0, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  RING_STAMP(2);
+
+  using V8 = typename Vec8<T>::type;
+  V8 a[2][FN], b[2][FM];
+  int rslot = 0, fslot = STAGES - 2;   // slots of tile kt and of tile kt + STAGES - 2
+  // One interval: the barrier that publishes tile kt, then this group's role.  G (the group) and PAR (kt & 1) are compile-time at
+  // each call site, so each group runs a straight-line body (a run-time role switch made the compiler merge the fragment registers of
+  // both roles through copies: 256 VGPRs + spills inside the loop).
+  auto interval = [&](auto G, auto PAR, int kt) {
+    constexpr int g = decltype(G)::value, par = decltype(PAR)::value;
+    // tile kt must have landed; tiles kt + 1 .. kt + STAGES - 3 (issued in the intervals since) may stay in flight
+    if (kt < nk) {
+      if (STAGES > 3 && kt + STAGES - 3 < nk) {
+        if (full) ring_wait_vmcnt<(STAGES - 3) * PPW>(); else ring_wait_vmcnt<(STAGES - 3) * (PPW - 1)>();
+      } else {
+        ring_wait_vmcnt<0>();
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt == 0) RING_STAMP(3);
+    if (kt == 4) RING_STAMP(4);
+    if constexpr (par == g) {
+      if (kt < nk) {   // this group's turn: the fragments of tile kt into registers (waited for by the MFMAs of the next interval)
+        const char* wb = smem + rslot * BUF + wn0 * ROWB;
+        const char* xb = smem + rslot * BUF + TN * ROWB + wm0 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < FN; ++i) a[ks][i] = lds_read8<T>(wb + i * 16 * ROWB + foff[ks]);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) b[ks][j] = lds_read8<T>(xb + j * 16 * ROWB + foff[ks]);
+        }
+      }
+    } else {
+      if (kt >= 1) {   // the MFMAs of tile kt - 1 (read in the previous interval)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<T>(a[ks][i], b[ks][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    if (kt + STAGES - 2 < nk) stage(fslot, kt + STAGES - 2);   // behind the reads / the MFMAs: the slot's last readers passed this barrier
+    rslot = rslot + 1 == STAGES ? 0 : rslot + 1;
+    fslot = fslot + 1 == STAGES ? 0 : fslot + 1;
+  };
+  auto run = [&](auto G) {
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt <= nk; kt += 2) {
+      interval(G, std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 <= nk) interval(G, std::integral_constant<int, 1>{}, kt + 1);
+    }
+  };
+  if (group == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+  RING_STAMP(5);
+
+  // ---- epilogue: the groups exchange halves of their partial sums (fragment f = i * FM + j belongs to group f & 1), each finishes its
+  //      half (bias, GELU, conversion) into a row-major tile in LDS, then every wave copies whole-row pieces out ----
+  __syncthreads();   // the ring is dead
+  {
+    static_assert((FN * FM) % 2 == 0, "fragments split evenly over the two groups");
+    constexpr int HALF = FN * FM / 2;
+    // outgoing fragments of group g of wave pair gw: [g][gw][HALF][64 lanes] f32x4
+    f32x4* out_red = reinterpret_cast<f32x4*>(smem) + ((size_t)(group * NWC + gw) * HALF) * 64 + lane;
+    const f32x4* in_red = reinterpret_cast<const f32x4*>(smem) + ((size_t)((group ^ 1) * NWC + gw) * HALF) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+        if (((i * FM + j) & 1) != group) out_red[((i * FM + j) >> 1) * 64] = acc[i][j];
+    __syncthreads();
+    char* tile = smem + RED_BYTES;
+    const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int nl = wn0 + i * 16 + ln;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EPI != EPI_RES_F32 && P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);   // RES_F32: bias and residual are inside group 0's accumulators
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if (((i * FM + j) & 1) != group) continue;
+        f32x4 v = acc[i][j] + in_red[((i * FM + j) >> 1) * 64] + bv;
+        if constexpr (EPI == EPI_GELU_OP) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        char* dst = tile + (wm0 + j * 16 + lm) * PITCH + nl * OSZ;
+        if constexpr (F32OUT) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          typename Vec4<T>::type o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+          *reinterpret_cast<typename Vec4<T>::type*>(dst) = o;
+        }
+      }
+    }
+  }
+  RING_STAMP(6);
+  __syncthreads();
+  {
+    constexpr int CPR = TN * OSZ / 16;            // 16-byte pieces per output row
+    constexpr int NCH = TM * CPR;
+    const char* tile = smem + RED_BYTES;
+    for (int q = tid; q < NCH; q += NT) {
+      const int row = q / CPR, c = q - row * CPR;
+      if (m0 + row >= M) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * PITCH + c * 16);
+      char* out = (char*)P.C + (view_off(P.c, m0 + row) + n0) * OSZ + c * 16;
+      *reinterpret_cast<f32x4*>(out) = v;
+    }
+  }
+  RING_STAMP(7);
+#undef RING_STAMP
+}
+
+// =================================================================================================
 // k128: two 128-deep buffers (256-byte rows) for the small projections (M <= 2048 rows)
 // =================================================================================================
 // The 64x64 / 128x128 launches of the 12-layer chain are latency-bound per K step (wait -> barrier ->
@@ -1211,12 +1439,42 @@ int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
   MRA_EPI_SWITCH((launch_k(gemm_k128_kernel<T, TN, TM, WGN, WGM, E>, a, WGN * WGM * 64, lds, stream)))
 }
 
+// the ring tiles (GemmProb::tile_cfg 9 / 10 / 11): 144 x 128, 192 x 128, 96 x 64 on 2 x 4 waves.  An epilogue whose staged tile does not fit
+// beside the group reduction in the ring's LDS (fp32 outputs of the two large tiles) is refused.
+template <int TN, int TM, int WGN, int WGM, int STAGES, int EPI>
+constexpr bool ring_fits() {
+  constexpr int osz = (EPI == EPI_RES_F32 || EPI == EPI_F32) ? 4 : 2;
+  return WGN * WGM * (TN / WGN / 16) * (TM / WGM / 16) * 1024 + TM * (TN * osz + 16) <= STAGES * (TN + TM) * 128;
+}
+template <typename T, int TN, int TM, int WGN, int WGM, int STAGES, int EPI>
+int launch_ring_epi(const GemmArgs& a, hipStream_t stream) {
+  if constexpr (ring_fits<TN, TM, WGN, WGM, STAGES, EPI>()) {
+    return launch_k(gemm_ring_kernel<T, TN, TM, WGN, WGM, STAGES, EPI>, a, 2 * WGN * WGM * 64, (size_t)STAGES * (TN + TM) * 128, stream);
+  } else {
+    return -2;
+  }
+}
+template <typename T, int TN, int TM, int WGN, int WGM, int STAGES>
+int launch_ring(const GemmArgs& a, int epi, hipStream_t stream) {
+  static_assert((size_t)STAGES * (TN + TM) * 128 <= 160 * 1024, "ring must fit the LDS");
+  switch (epi) {
+    case EPI_OP: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_OP>(a, stream);
+    case EPI_GELU_OP: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_GELU_OP>(a, stream);
+    case EPI_RES_F32: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_RES_F32>(a, stream);
+    case EPI_F32: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_F32>(a, stream);
+    default: return -2;
+  }
+}
+
 #ifdef MRA_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
 #endif
 
 template <typename T>
 int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
+  if (cfg == 8) return counted(GF_RING_144x128, epi, launch_ring<T, 144, 128, 1, 4, 4>(a, epi, stream));   // a wave: all 144 weight rows x 32 activation rows
+  if (cfg == 9) return counted(GF_RING_192x128, epi, launch_ring<T, 192, 128, 2, 2, 4>(a, epi, stream));
+  if (cfg == 10) return counted(GF_RING_96x64, epi, launch_ring<T, 96, 64, 2, 2, 7>(a, epi, stream));
   if (cfg == 3) return counted(GF_WS_128x384, epi, launch_ws_fold<T>(a, epi, stream));
   if (cfg == 4) return counted(GF_WS_176x384, epi, launch_ws_pv<T>(a, epi, stream));
   if (cfg == 5) return counted(GF_K128_64x128, epi, launch_k128<T, 64, 128, 2, 2>(a, epi, stream));   // 64 weight rows x 128 activation rows, 128-deep steps
@@ -1260,8 +1518,8 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
 }
 
 constexpr int kTile[3] = {64, 128, 256};
-constexpr int kTileN[8] = {64, 128, 256, 128, 176, 64, 128, 256};   // weight rows per tile (config 7: 256, then 128 for the last column tile)
-constexpr int kTileM[8] = {64, 128, 256, 384, 384, 128, 512, 256};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
+constexpr int kTileN[11] = {64, 128, 256, 128, 176, 64, 128, 256, 144, 192, 96};   // weight rows per tile (config 7: 256, then 128 for the last column tile)
+constexpr int kTileM[11] = {64, 128, 256, 384, 384, 128, 512, 256, 128, 128, 64};   // activation rows per tile (config 3: explicit only, GemmProb::tile_cfg = 4)
 
 }  // namespace
 
@@ -1305,7 +1563,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
   if (ngroups < 1 || ngroups > 2) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
-  if (cfg < 0 || cfg > 7) return -1;
+  if (cfg < 0 || cfg > 10) return -1;
   const int t = kTileN[cfg], tm = kTileM[cfg];
   GemmArgs a;
   a.ngroups = ngroups;
@@ -1316,6 +1574,8 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask && cfg != 7)) return -1;
     if (cfg == 5 && p.K % 128) return -1;
+    if (cfg >= 8 && (p.n_ragged || p.n_mask || p.batch > 1 || p.w_ld || (epi != EPI_OP && epi != EPI_GELU_OP && epi != EPI_RES_F32 && epi != EPI_F32))) return -1;   // ring tiles: plain problems
+    if (cfg >= 8 && (epi == EPI_RES_F32 || epi == EPI_F32) && ((p.c.ld & 3) || (p.c.item_stride & 3))) return -1;   // their outputs leave as 16-byte pieces
     if (cfg == 6 && (p.K % 128 || p.N != 128 || p.n_mask || p.n_ragged || p.batch > 1)) return -1;   // the eight-phase tail tile: one column tile, even K steps
     if (cfg == 7 && (p.K % 128 || p.N % 256 != 128 || p.N < 384 || p.n_mask || p.n_ragged || p.batch > 1 || ngroups != 1)) return -1;
     if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32 && epi != EPI_RES_OP && epi != EPI_OP && epi != EPI_GELU_OP) || (p.N & 3) || p.n_ragged)) return -1;

@@ -80,7 +80,9 @@ struct GemmProb {
                    // the layer chain at ~1 k rows, where a tile's bytes per flop, not its count, sets the time), 7 = 128 (weight rows) x 512
                    // (activation rows) on the eight-phase kernel (N = 128 exactly: the half-width last column tile of N = 256 k + 128, launched on its
                    // own with W / bias / C / R offset to those columns; EPI_RES_F32 / EPI_F32 / EPI_RES_OP, K % 128 == 0), 8 = N = 256 k + 128 in ONE launch:
-                   // full 256 x 256 eight-phase tiles plus one 128 x 512 tail tile per pair of row tiles (same epilogues, one problem); the first problem decides
+                   // full 256 x 256 eight-phase tiles plus one 128 x 512 tail tile per pair of row tiles (same epilogues, one problem); the first problem decides;
+                   // 9 / 10 / 11 = the ring kernel's exact-fit tiles of the layer chain: 144 (weight rows) x 128 (activation rows), 192 x 128, 96 x 64 -- one
+                   // workgroup per CU at 2048 x 2304, 2 x 1024 x 3072 and 2048 x 768 (plain problems, N a multiple of the tile, EPI_OP / GELU_OP / RES_F32 / F32)
   int order;       // tile walk: 0 = panels of 8 row tiles, rows fastest; gn > 0 = panels of gn column tiles walked down the rows, columns
                    // fastest (measured better for the ViT's N = 1408 GEMMs: all 6 column tiles of a row tile run together)
   int tile_begin;  // filled by the launcher
@@ -110,7 +112,8 @@ enum GemmFamily {
   GF_K128_64x128 = 7,                           // gemm_k128_kernel, 128-deep steps
   GF_P8_TAIL = 8, GF_P8_MIXED = 9,              // eight-phase 128 x 512 tail tile; full tiles + tail tile in one launch
   GF_K128_64x64 = 10,
-  GEMM_FAMILIES = 11
+  GF_RING_144x128 = 11, GF_RING_192x128 = 12, GF_RING_96x64 = 13,   // gemm_ring_kernel: exact-fit tiles of the layer chain, K tiles through an LDS ring
+  GEMM_FAMILIES = 14
 };
 long long gemm_launch_count(int family, int epi);
 #ifdef MRA_GEMM_EXPERIMENTS

@@ -494,6 +494,8 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       // not by tile count: 128 x 128 tiles (288 of them) move half the bytes per flop of the 1152 64 x 64 tiles the automatic
       // choice makes (headline step 6.75 -> 6.67 ms, reference item shape 2.65 -> 2.55 ms together with the down-projection below)
       p.tile_cfg = N * S >= 1024 ? 2 : 0;
+      // ... and at ~2 k rows the ring kernel's 144 x 128 tile is exactly one workgroup per CU (2048 x 2304 = 16 x 16 tiles): 14.4 vs 17.6 us stand-alone
+      if ((h->chain_ring & 1) && N * S >= 1024 && (3 * H) % 144 == 0) p.tile_cfg = 9;
       rc = launch_gemm(&p, 1, EPI_OP, op, stream);
       if (rc) return chk(rc, "qkv gemm");
     }
@@ -522,6 +524,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       p.R = w.hA32; p.r = all_rows;
       p.C = w.pre32; p.c = all_rows;
       p.M = N * S; p.N = H; p.K = H;
+      if ((h->chain_ring & 4) && N * S >= 1024 && H % 96 == 0) p.tile_cfg = 11;
       rc = launch_gemm(&p, 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "attn out gemm");
       rc = launch_ln_rows(w.pre32, all_rows, N * S, H, Lw.ln1g, Lw.ln1b, c.ln_eps, w.hB32, all_rows, w.hB16, all_rows, op,
@@ -704,6 +707,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       g[1].W = Lw.wit; g[1].bias = Lw.bit;
       g[1].C = w.ffn16 + (size_t)N * Q * I * esz; g[1].c = plain(text_rows, I);
       g[1].M = text_rows; g[1].N = I; g[1].K = H;
+      if ((h->chain_ring & 2) && N * Q >= 512 && I % 192 == 0) g[0].tile_cfg = 10;
       rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_GELU_OP, op, stream);
       if (rc) return chk(rc, "ffn up gemm");
     }
@@ -720,6 +724,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       g[1].C = w.pre32 + t_off32; g[1].c = tv;
       g[1].M = text_rows; g[1].N = H; g[1].K = I;
       g[0].tile_cfg = N * Q >= 512 && I % 128 == 0 ? 6 : 0;   // 64 weight rows x 128 activation rows, 128-deep K steps (see the QKV note)
+      if ((h->chain_ring & 4) && N * Q >= 512 && H % 96 == 0) g[0].tile_cfg = 11;
       rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "ffn down gemm");
     }
@@ -837,6 +842,17 @@ int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode) {
   }
   h->cross_precise = mode;
   return MRA_OK;
+}
+
+int mra_qformer_set_option(mra_qformer* h, const char* name, int32_t value) {
+  if (!h || !name) return fail(MRA_EINVAL, "null argument");
+  const std::string key(name);
+  if (key == "chain_ring") {
+    if (value < 0 || value > 7) return fail(MRA_EINVAL, "chain_ring is a mask of bits 0-2");
+    h->chain_ring = value;
+    return MRA_OK;
+  }
+  return fail(MRA_ENAME, "unknown option: " + key);
 }
 
 int mra_qformer_set_kv_done_event(mra_qformer* h, void* ev) {

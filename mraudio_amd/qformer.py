@@ -363,6 +363,10 @@ class QFormer(nn.Module):
         code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4, "fold_rescale_pass": 5}.get(mode, mode)
         check(lib().mra_qformer_set_cross_mode(self._handle, int(code)), "mra_qformer_set_cross_mode")
 
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle tuning option (``mra_qformer_set_option``), e.g. ``("chain_ring", mask)``."""
+        check(lib().mra_qformer_set_option(self._handle, name.encode(), int(value)), f"mra_qformer_set_option({name})")
+
     def set_cross_precision(self, mode) -> None:
         """Precision of the cross-attention score chain: ``"op"`` (default: f16 / bf16 operands) or ``"split"`` (hidden state, W_cq, Q,
         W_k and Q' as hi + lo pairs, ~22 bits; folded form at any Kv; ``mra_qformer_set_cross_precision``).  For sharply attending

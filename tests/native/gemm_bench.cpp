@@ -224,7 +224,7 @@ static void chain_ab(int rounds) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& sh : shapes) {
     printf("%-30s", sh.name);
-    for (int cfg : {1, 2, 6}) {
+    for (int cfg : {1, 2, 6, 9, 10, 11}) {
       GemmProb q[2];
       for (int g = 0; g < sh.groups; ++g) {
         q[g] = GemmProb{};
@@ -233,6 +233,7 @@ static void chain_ab(int rounds) {
         q[g].M = sh.M; q[g].N = sh.N; q[g].K = sh.K; q[g].tile_cfg = cfg;
       }
       if (cfg == 6 && sh.K % 128) { printf("  cfg6   n/a"); continue; }
+      if ((cfg == 9 && sh.N % 144) || (cfg == 10 && sh.N % 192) || (cfg == 11 && sh.N % 96)) { printf("  cfg%-2d  n/a   ", cfg); continue; }
       double best = 1e30;
       bool ok = true;
       for (int r = 0; r < rounds && ok; ++r) {
@@ -248,6 +249,50 @@ static void chain_ab(int rounds) {
       if (ok) printf("  cfg%d %5.1f us", cfg, best); else printf("  cfg%d refused", cfg);
     }
     printf("\n");
+  }
+}
+
+// stamped timeline of the ring kernel on the QKV shape (2048 x 768 -> 2304, 256 workgroups of 144 x 128): wall clock (10 ns ticks) relative to the
+// earliest workgroup start, mean / min / max over the workgroups' wave 0 and wave 4
+static void ring_stamp() {
+  const int M = 2048, N = 2304, K = 768;
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)N * K);
+  for (auto& v : h) v = (_Float16)d(rng);
+  _Float16 *A, *W, *C;
+  float* bias;
+  CK(hipMalloc((void**)&A, h.size() * 2)); CK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&W, h.size() * 2)); CK(hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C, (size_t)M * N * 2)); CK(hipMalloc((void**)&bias, N * 4)); CK(hipMemset(bias, 0, N * 4));
+  unsigned long long* dbg;
+  const size_t nent = (size_t)256 * 8 * 16;
+  CK(hipMalloc((void**)&dbg, nent * 8));
+  GemmProb p{};
+  p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.C = C; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.tile_cfg = 9;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(dbg, 0, nent * 8));
+    gemm_set_debug_buffer(dbg);
+    for (int i = 0; i < 3; ++i) launch_gemm(&p, 1, EPI_OP, OP_F16, 0);   // the last launch's stamps stay
+    CK(hipDeviceSynchronize());
+    gemm_set_debug_buffer(nullptr);
+    std::vector<unsigned long long> s(nent);
+    CK(hipMemcpy(s.data(), dbg, nent * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < 256; ++b) t0 = std::min(t0, s[((size_t)b * 8) * 16]);
+    const char* names[8] = {"start", "touches issued", "prologue staged", "barrier 0 passed", "barrier 4 passed", "K loop done", "groups reduced", "end"};
+    for (int w : {0, 4}) {
+      printf("wave %d (wall clock, us after the first workgroup's start; shader cycles since this wave's start):\n", w);
+      for (int e = 0; e < 8; ++e) {
+        double sum = 0, mn = 1e30, mx = 0, cyc = 0;
+        for (int b = 0; b < 256; ++b) {
+          const unsigned long long* q = &s[((size_t)b * 8 + w) * 16];
+          const double us = (double)(q[e] - t0) * 0.01;
+          sum += us; mn = std::min(mn, us); mx = std::max(mx, us); cyc += (double)(q[8 + e] - q[8]);
+        }
+        printf("  %-18s mean %6.2f  min %6.2f  max %6.2f   cycles %8.0f\n", names[e], sum / 256, mn, mx, cyc / 256);
+      }
+    }
   }
 }
 
@@ -314,6 +359,7 @@ int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   if (argc > 2 && !strcmp(argv[2], "race")) { race_screen(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "chain")) { chain_ab(rounds); return 0; }
+  if (argc > 2 && !strcmp(argv[2], "stamp")) { ring_stamp(); return 0; }
   if (argc > 2 && !strcmp(argv[2], "splitk")) { splitk_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "fold")) { fold_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "order")) { order_ab(rounds); return 0; }

@@ -1062,6 +1062,21 @@ int main(int argc, char** argv) {
   test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);
   test_gemm(7, EPI_RES_F32, OP_F16, 700, 1408, 1408, false);
+  // the ring kernel's exact-fit tiles (tile_cfg 9 / 10 / 11): every epilogue, ragged M, row views, two problems, 1 .. 48 K steps (fewer than,
+  // exactly, and many more than the ring holds)
+  test_gemm(8, EPI_OP, OP_F16, 2 * 128 + 37, 288, 192, true);
+  test_gemm(8, EPI_OP, OP_F16, 700, 144, 768, false);
+  test_gemm(8, EPI_GELU_OP, OP_F16, 100, 288, 256, false);
+  test_gemm(8, EPI_OP, OP_BF16, 300, 144, 128, false, 2);
+  test_gemm(8, EPI_OP, OP_F16, 128 + 5, 432, 64, true, 2);
+  test_gemm(9, EPI_GELU_OP, OP_F16, 2 * 128 + 37, 384, 768, true, 2);
+  test_gemm(9, EPI_OP, OP_BF16, 128, 192, 64, false);
+  test_gemm(9, EPI_OP, OP_F16, 500, 576, 128, true);
+  test_gemm(10, EPI_RES_F32, OP_F16, 3 * 64 + 11, 192, 3072, true, 2);
+  test_gemm(10, EPI_RES_F32, OP_F16, 500, 768, 768, false);
+  test_gemm(10, EPI_OP, OP_F16, 200, 96, 448, true);
+  test_gemm(10, EPI_F32, OP_BF16, 64, 288, 64, false);
+  test_gemm(10, EPI_GELU_OP, OP_F16, 70, 96, 384, false);
   // an odd number of K steps takes the loader-wave 256 x 256 kernel (8 compute + 4 loader waves)
   test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1344, false);   // GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
