@@ -1034,13 +1034,14 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
   constexpr int WTN = TN / WGN, WTM = TM / WGM, FN = WTN / 16, FM = WTM / 16;
   constexpr int ROWS = TN + TM, NPIECE = ROWS / 8, PPW = (NPIECE + NW - 1) / NW;   // 1 KiB pieces per K tile / per wave (upper bound)
   constexpr int BUF = ROWS * ROWB;
-  constexpr bool F32OUT = EPI == EPI_RES_F32 || EPI == EPI_F32;
+  constexpr bool RESID = EPI == EPI_RES_F32 || EPI == EPI_RES_LN;
+  constexpr bool F32OUT = RESID || EPI == EPI_F32;
   constexpr int OSZ = F32OUT ? 4 : 2, PITCH = TN * OSZ + 16;                         // staged output tile: row-major, padded rows
   constexpr int RED_BYTES = NWC * FN * FM * 1024;
   static_assert(TN % (16 * WGN) == 0 && TM % (16 * WGM) == 0 && ROWS % 8 == 0 && TN % 8 == 0, "tile must split over the waves; whole pieces");
   static_assert(STAGES >= 4 && (STAGES - 3) * PPW <= 63, "vmcnt holds 6 bits");
   static_assert(RED_BYTES + TM * PITCH <= STAGES * BUF, "reduction + staged tile reuse the ring");
-  static_assert(EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_RES_F32 || EPI == EPI_F32, "epilogues of the ring kernel");
+  static_assert(EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_RES_F32 || EPI == EPI_F32 || EPI == EPI_RES_LN, "epilogues of the ring kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1095,7 +1096,7 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
     foff[ks] = r * ROWB + c * 16;
   }
   f32x4 acc[FN][FM];
-  if (EPI == EPI_RES_F32 && group == 0) {
+  if (RESID && group == 0) {
     // ordinary loads behind the prologue's DMA: the bias add below makes the compiler wait for them with vmcnt(0), which also covers the
     // prologue's tiles (one round trip for both); nothing of them stays in the queue the loop counts
     accumulators_from_residual<FN, FM>(P, acc, n0 + wn0, m0 + wm0, lane);
@@ -1187,7 +1188,7 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
     for (int i = 0; i < FN; ++i) {
       const int nl = wn0 + i * 16 + ln;
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (EPI != EPI_RES_F32 && P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);   // RES_F32: bias and residual are inside group 0's accumulators
+      if (!RESID && P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);   // RES_F32 / RES_LN: bias and residual are inside group 0's accumulators
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         if (((i * FM + j) & 1) != group) continue;
@@ -1219,7 +1220,85 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
       if (m0 + row >= M) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * PITCH + c * 16);
       char* out = (char*)P.C + (view_off(P.c, m0 + row) + n0) * OSZ + c * 16;
-      *reinterpret_cast<f32x4*>(out) = v;
+      if constexpr (EPI == EPI_RES_LN) {
+        // read by ANOTHER workgroup, possibly on another XCD (whose L2 is not coherent with this one's): sc1 = written through
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out), "v"(v) : "memory");
+      } else {
+        *reinterpret_cast<f32x4*>(out) = v;
+      }
+    }
+  }
+  if constexpr (EPI == EPI_RES_LN) {
+    // LayerNorm by the last-arriving column tile of this row block (MI355X_MICROARCH.md, inter-workgroup visibility: every store sc1 and
+    // drained by its wave, the workgroup's barrier, ONE agent-scope atomic add; the workgroup whose add came last -- told by the value
+    // returned -- reads the bytes with sc1 loads after a barrier behind that add).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);   // the reduction space is dead
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(P.ln_counter + m0 / TM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = old == (unsigned)(P.ntiles - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag) {
+      // every wave normalises TM / NW rows; ALL their loads go out before the one wait (a round trip per row in series cost ~2 us each)
+      constexpr int RPW = (TM + NW - 1) / NW;
+      const int H = P.N;                       // 256 * NV columns, NV = 1 .. 4
+      const int nv = H >> 8;
+      f32x4 v[RPW][4];
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        const int m = min(m0 + wave + u * NW, M - 1);
+        const float* xr = (const float*)P.C + view_off(P.c, m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (i < nv) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][i]) : "v"(xr + (i * 64 + lane) * 4) : "memory");
+        }
+      }
+      f32x4 g[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = min(i, nv - 1) * 256 + lane * 4;
+        g[i] = *reinterpret_cast<const f32x4*>(P.ln_gain + c);
+        b[i] = *reinterpret_cast<const f32x4*>(P.ln_bias + c);
+      }
+#pragma unroll
+      for (int u = 0; u < RPW; ++u)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory");
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        const int r = wave + u * NW;
+        const int m = m0 + r;
+        if (r >= TM || m >= M) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nv) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
+        const float mean = wave_sum(sum) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[u][i][e] -= mean; q += v[u][i][e] * v[u][i][e]; }
+          }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + P.ln_eps);
+        float* o32 = P.ln_y32 ? P.ln_y32 + view_off(P.ln_y32v, m) : nullptr;
+        T* o16 = P.ln_y16 ? (T*)P.ln_y16 + view_off(P.ln_y16v, m) : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4 y;
+            typename Vec4<T>::type y16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y[e] = v[u][i][e] * rstd * g[i][e] + b[i][e]; y16[e] = from_f32<T>(y[e]); }
+            if (o32) *reinterpret_cast<f32x4*>(o32 + c) = y;
+            if (o16) *reinterpret_cast<typename Vec4<T>::type*>(o16 + c) = y16;
+          }
+      }
+      if (tid == 0) P.ln_counter[m0 / TM] = 0u;   // ready for the next launch (visible at the launch boundary)
     }
   }
   RING_STAMP(7);
@@ -1443,7 +1522,7 @@ int launch_k128(const GemmArgs& a, int epi, hipStream_t stream) {
 // beside the group reduction in the ring's LDS (fp32 outputs of the two large tiles) is refused.
 template <int TN, int TM, int WGN, int WGM, int STAGES, int EPI>
 constexpr bool ring_fits() {
-  constexpr int osz = (EPI == EPI_RES_F32 || EPI == EPI_F32) ? 4 : 2;
+  constexpr int osz = (EPI == EPI_RES_F32 || EPI == EPI_F32 || EPI == EPI_RES_LN) ? 4 : 2;
   return WGN * WGM * (TN / WGN / 16) * (TM / WGM / 16) * 1024 + TM * (TN * osz + 16) <= STAGES * (TN + TM) * 128;
 }
 template <typename T, int TN, int TM, int WGN, int WGM, int STAGES, int EPI>
@@ -1462,6 +1541,9 @@ int launch_ring(const GemmArgs& a, int epi, hipStream_t stream) {
     case EPI_GELU_OP: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_GELU_OP>(a, stream);
     case EPI_RES_F32: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_RES_F32>(a, stream);
     case EPI_F32: return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_F32>(a, stream);
+    case EPI_RES_LN:
+      if constexpr (TN == 96) return launch_ring_epi<T, TN, TM, WGN, WGM, STAGES, EPI_RES_LN>(a, stream);   // the residual projections' tile only
+      else return -2;
     default: return -2;
   }
 }
@@ -1574,8 +1656,11 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.K % 64 || (p.N % t && !p.n_ragged && !p.n_mask && cfg != 7)) return -1;
     if (cfg == 5 && p.K % 128) return -1;
-    if (cfg >= 8 && (p.n_ragged || p.n_mask || p.batch > 1 || p.w_ld || (epi != EPI_OP && epi != EPI_GELU_OP && epi != EPI_RES_F32 && epi != EPI_F32))) return -1;   // ring tiles: plain problems
-    if (cfg >= 8 && (epi == EPI_RES_F32 || epi == EPI_F32) && ((p.c.ld & 3) || (p.c.item_stride & 3))) return -1;   // their outputs leave as 16-byte pieces
+    if (cfg >= 8 && (p.n_ragged || p.n_mask || p.batch > 1 || p.w_ld || (epi != EPI_OP && epi != EPI_GELU_OP && epi != EPI_RES_F32 && epi != EPI_F32 && epi != EPI_RES_LN))) return -1;   // ring tiles: plain problems
+    if (cfg >= 8 && (epi == EPI_RES_F32 || epi == EPI_F32 || epi == EPI_RES_LN) && ((p.c.ld & 3) || (p.c.item_stride & 3))) return -1;   // their outputs leave as 16-byte pieces
+    if (epi == EPI_RES_LN && (cfg != 10 || !p.R || p.r.rpi <= 0 || !p.ln_gain || !p.ln_bias || !p.ln_counter || (!p.ln_y32 && !p.ln_y16) || p.N % 256 || p.N > 1024 ||
+                              (p.ln_y32 && (p.ln_y32v.rpi <= 0 || (p.ln_y32v.ld & 3) || (p.ln_y32v.item_stride & 3))) ||
+                              (p.ln_y16 && (p.ln_y16v.rpi <= 0 || (p.ln_y16v.ld & 3) || (p.ln_y16v.item_stride & 3))))) return -1;
     if (cfg == 6 && (p.K % 128 || p.N != 128 || p.n_mask || p.n_ragged || p.batch > 1)) return -1;   // the eight-phase tail tile: one column tile, even K steps
     if (cfg == 7 && (p.K % 128 || p.N % 256 != 128 || p.N < 384 || p.n_mask || p.n_ragged || p.batch > 1 || ngroups != 1)) return -1;
     if (p.n_mask && ((epi != EPI_RES_F32 && epi != EPI_F32 && epi != EPI_RES_OP && epi != EPI_OP && epi != EPI_GELU_OP) || (p.N & 3) || p.n_ragged)) return -1;
@@ -1588,6 +1673,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
+    if (epi == EPI_RES_LN && cfg != 10) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_RES_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
     if (epi == EPI_RES_OP && (!p.aux || p.n_ragged)) return -1;

@@ -19,6 +19,10 @@ enum GemmEpi {
   EPI_GELU_BWD = 7,  // training backward: C(op dtype) = acc * gelu'(aux): the GELU gradient inside the data-gradient GEMM
   EPI_RES_OP = 8,   // C(op dtype) = op(acc + bias) + Rop: residual stream kept in the operand dtype (the ViT under precision="fp16");
                     // Rop is GemmProb::aux (op dtype, addressed like C; may alias C: updated in place)
+  EPI_RES_LN = 9,   // EPI_RES_F32 followed by the LayerNorm of the finished rows INSIDE the launch (ring tiles only): the column tile of a row block
+                    // that finishes last (agent-scope counter GemmProb::ln_counter, one per row tile, zero before the launch, reset by the kernel)
+                    // normalises the block's rows and writes ln_y32 / ln_y16 -- the reference's `LayerNorm(dense(x) + residual)` (HF:519-530,
+                    // 573-587) in one launch.  C still receives the pre-LayerNorm rows (sc1 stores: other XCDs read them).
   EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile
                     // sum go to stat_m / stat_l [row][ntiles] (176 x 384 loader-wave tile only: a wave holds whole tile rows)
 };
@@ -60,6 +64,15 @@ struct GemmProb {
   // matrix, e.g. the encoder tokens themselves for P . enc); rows k >= k_rows are read from row k_rows - 1 (the A operand
   // is zero there).  The kernel stages [64 k][176 n] tiles and takes its fragments with ds_read_b64_tr_b16.
   int w_ld, k_rows;
+  // EPI_RES_LN: LayerNorm over the N columns of every finished row (N = 256 k <= 1024): y = (x - mean) * rstd * ln_gain + ln_bias, biased variance,
+  // fp32; outputs ln_y32 (fp32, row view ln_y32v; may be null) and ln_y16 (operand dtype, row view ln_y16v; may be null)
+  const float* ln_gain;
+  const float* ln_bias;
+  float ln_eps;
+  float* ln_y32;
+  void* ln_y16;
+  RowView ln_y32v, ln_y16v;
+  unsigned* ln_counter;   // [ceil(M / tile rows)] zero before the launch; the kernel leaves it zero
   // w_kwrap > 0 (loader-wave kernels, row-major W): W holds only w_kwrap K steps of 64 (K = 2 * 64 * w_kwrap) and is walked twice -- C = [A_hi | A_lo] . [W | W]^T,
   // the scores product of the split-precision cross-attention (Q' kept as an f16 hi + lo pair against the same encoder slab)
   int w_kwrap;

@@ -150,6 +150,8 @@ struct Work {
   char *encT, *qp16, *p16, *u16;   // folded cross-attention: enc^T [N][E][kvp], Q' [N][R][E], P [N][R][kvp], U [N][R][E]
   char *hs16, *qs16;               // split-precision cross-attention: (hi | lo | hi) of the query rows [N*Q][3H] and of Q per head [N*Q][heads][192]
   float *qc32, *qp32;              // ... Q [N*Q][H] and Q' [N][R][E] in f32 (then Q' leaves as (hi | lo) rows [N][R][2E] in qp16)
+  unsigned* lncnt;                 // fused residual + LayerNorm: one counter per 64-row tile and problem (zeroed at the start of a forward)
+  size_t lncnt_bytes;
   float* s32;                      // scores [N][R][kvp]
   float* stat;                     // split softmax: tile maxima [N][R][ntiles], then tile sums
   float* gfac;                     // split softmax: row factors exp2(m_tile - m_row) / L as [N][ntiles][512] for the P . enc GEMM
@@ -175,6 +177,8 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
   w.qc16 = cv.take<char>(N * Q * H, 2);
   w.hC16 = cv.take<char>(N * Q * H, 2);
   w.ffn16 = cv.take<char>(N * S * I, 2);
+  w.lncnt_bytes = 2 * ((size_t)N * S / 64 + 2) * sizeof(unsigned);
+  w.lncnt = cv.take<unsigned>(w.lncnt_bytes / sizeof(unsigned));
   w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = w.hs16 = w.qs16 = nullptr;
   w.qc32 = w.qp32 = nullptr;
   w.s32 = w.stat = w.gfac = w.st_m = w.st_l = w.ginv = nullptr;
@@ -458,6 +462,9 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
                            h->embb, c.ln_eps, w.hA32, w.hA16, nullptr, op, stream);
   if (rc) return chk(rc, "embed_ln");
 
+  // residual projection + LayerNorm in ONE launch (chain_ring bit 3, on the 96 x 64 ring tile): its per-row-tile counters start at zero
+  const bool ln_fuse = (h->chain_ring & 12) == 12 && H % 96 == 0 && H % 256 == 0 && H <= 1024;
+  if (ln_fuse) HIP_TRY(hipMemsetAsync(w.lncnt, 0, w.lncnt_bytes, stream));
   const bool fold = h->ncross > 0 && use_fold(h, kv);
   const bool stream_fold = fold && fold_streams(h, kv);
   const int R = c.heads * Q, kvp = fold_kvp(kv);
@@ -525,11 +532,19 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       p.C = w.pre32; p.c = all_rows;
       p.M = N * S; p.N = H; p.K = H;
       if ((h->chain_ring & 4) && N * S >= 1024 && H % 96 == 0) p.tile_cfg = 11;
+      if (ln_fuse && p.tile_cfg == 11) {
+        // HF:519-530 in one launch: the column tile of a 64-row block that finishes last normalises the block's rows
+        p.ln_gain = Lw.ln1g; p.ln_bias = Lw.ln1b; p.ln_eps = c.ln_eps;
+        p.ln_y32 = w.hB32; p.ln_y32v = all_rows; p.ln_y16 = w.hB16; p.ln_y16v = all_rows; p.ln_counter = w.lncnt;
+        rc = launch_gemm(&p, 1, EPI_RES_LN, op, stream);
+        if (rc) return chk(rc, "attn out gemm + ln");
+      } else {
       rc = launch_gemm(&p, 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "attn out gemm");
       rc = launch_ln_rows(w.pre32, all_rows, N * S, H, Lw.ln1g, Lw.ln1b, c.ln_eps, w.hB32, all_rows, w.hB16, all_rows, op,
                           stream);
       if (rc) return chk(rc, "attn ln");
+      }
     }
     // query-side state entering the feed-forward: hB[:, :32] or the cross-attention output hC
     const void* fq16 = w.hB16;
@@ -679,11 +694,19 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       o.R = w.hB32; o.r = q_view;
       o.C = w.pre32; o.c = qc_rows;
       o.M = N * Q; o.N = H; o.K = H;
+      if (ln_fuse && N * Q >= 512) {
+        o.tile_cfg = 11;
+        o.ln_gain = Lw.lncg; o.ln_bias = Lw.lncb; o.ln_eps = c.ln_eps;
+        o.ln_y32 = w.hC32; o.ln_y32v = qc_rows; o.ln_y16 = w.hC16; o.ln_y16v = qc_rows; o.ln_counter = w.lncnt;
+        rc = launch_gemm(&o, 1, EPI_RES_LN, op, stream);
+        if (rc) return chk(rc, "cross out gemm + ln");
+      } else {
       rc = launch_gemm(&o, 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "cross out gemm");
       rc = launch_ln_rows(w.pre32, qc_rows, N * Q, H, Lw.lncg, Lw.lncb, c.ln_eps, w.hC32, qc_rows, w.hC16, qc_rows, op,
                           stream);
       if (rc) return chk(rc, "cross ln");
+      }
       fq16 = w.hC16;
       fq32 = w.hC32;
       fqv = qc_rows;
@@ -695,6 +718,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       if (!last || want_text_last) text_rows = N * L;
       else if (want_cls_last) { text_rows = N; tv = cls_view; }
     }
+    bool ffn_ln_fused = false;
     const size_t t_off16 = (size_t)Q * H * esz;   // byte offset of row 32 inside an item (op dtype)
     const size_t t_off32 = (size_t)Q * H;         // element offset (f32)
     {
@@ -725,10 +749,24 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
       g[1].M = text_rows; g[1].N = H; g[1].K = I;
       g[0].tile_cfg = N * Q >= 512 && I % 128 == 0 ? 6 : 0;   // 64 weight rows x 128 activation rows, 128-deep K steps (see the QKV note)
       if ((h->chain_ring & 4) && N * Q >= 512 && H % 96 == 0) g[0].tile_cfg = 11;
+      ffn_ln_fused = ln_fuse && !last && g[0].tile_cfg == 11;
+      if (ffn_ln_fused) {
+        // HF:573-587 for both row sets in the same launch: problem 0 = query rows (output_query.LayerNorm), problem 1 = text rows (output.LayerNorm)
+        g[0].ln_gain = Lw.lnqg; g[0].ln_bias = Lw.lnqb; g[0].ln_eps = c.ln_eps;
+        g[0].ln_y32 = w.hA32; g[0].ln_y32v = q_view; g[0].ln_y16 = w.hA16; g[0].ln_y16v = q_view; g[0].ln_counter = w.lncnt;
+        g[1].ln_gain = Lw.lntg; g[1].ln_bias = Lw.lntb; g[1].ln_eps = c.ln_eps;
+        g[1].ln_y32 = w.hA32 + t_off32; g[1].ln_y32v = tv; g[1].ln_y16 = w.hA16 + t_off16; g[1].ln_y16v = tv;
+        g[1].ln_counter = w.lncnt + (N * Q + 63) / 64;
+        rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_LN, op, stream);
+        if (rc) return chk(rc, "ffn down gemm + ln");
+      } else {
       rc = launch_gemm(g, text_rows > 0 ? 2 : 1, EPI_RES_F32, op, stream);
       if (rc) return chk(rc, "ffn down gemm");
+      }
     }
-    if (!last && text_rows == N * L && L > 0) {
+    if (ffn_ln_fused) {
+      // the LayerNorms ran inside the down-projection's launch
+    } else if (!last && text_rows == N * L && L > 0) {
       // query and text LayerNorm in one launch: the two row sets are the whole [N, S, H] stream
       rc = launch_ln_rows2(w.pre32, all_rows, N * S, H, Lw.lnqg, Lw.lnqb, Lw.lntg, Lw.lntb, S, Q, c.ln_eps, w.hA32, all_rows,
                            w.hA16, all_rows, op, stream);
@@ -848,7 +886,7 @@ int mra_qformer_set_option(mra_qformer* h, const char* name, int32_t value) {
   if (!h || !name) return fail(MRA_EINVAL, "null argument");
   const std::string key(name);
   if (key == "chain_ring") {
-    if (value < 0 || value > 7) return fail(MRA_EINVAL, "chain_ring is a mask of bits 0-2");
+    if (value < 0 || value > 15) return fail(MRA_EINVAL, "chain_ring is a mask of bits 0-3");
     h->chain_ring = value;
     return MRA_OK;
   }

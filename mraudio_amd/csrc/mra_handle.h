@@ -103,8 +103,10 @@ struct mra_qformer {
   // hi + lo pairs (folded form forced); wk32 = f32 copies of the key weights [ncross][H][E], arena_p = per cross layer W_cq as
   // [H][3H] (hi | hi | lo) and W_k as [heads][E][192] (hi | hi | lo), allocated when the mode is first enabled
   // layer-chain GEMMs on the ring kernel's exact-fit tiles (mra_qformer_set_option "chain_ring"): bit 0 QKV (144 x 128), bit 1 FFN-up (192 x 128),
-  // bit 2 the N = hidden projections with a residual (96 x 64); chosen per launch only where the tile divides N and the launch has >= ~1 k rows
-  int chain_ring = 7;   // measured in the step (r03d, same box): mask 0 / 1 / 3 / 7 = 6.65 / 6.64 / 6.59 / 6.56 ms; reference item shape 2.55 / 2.62 / - / 2.52 ms
+  // bit 2 the N = hidden projections with a residual (96 x 64), bit 3 (with bit 2) their LayerNorm inside the same launch (EPI_RES_LN: measured
+  // SLOWER in the step -- 6.95 vs 6.73-6.93 ms, reference item shape 2.86-2.92 vs 2.65-2.83 -- opt-in); chosen per launch only where the tile
+  // divides N and the launch has >= ~1 k rows
+  int chain_ring = 7;    // measured in the step (r03d, same box): mask 0 / 1 / 3 / 7 = 6.65 / 6.64 / 6.59 / 6.56 ms; reference item shape 2.55 / 2.62 / - / 2.52 ms
   int cross_precise = 0;
   float* wk32 = nullptr;
   char* arena_p = nullptr;

@@ -346,6 +346,75 @@ static void test_gemm_kmajor(int op, int M, int N, int K, int k_rows, int batch)
   report(name, worst, 3e-3);
 }
 
+// EPI_RES_LN on the 96 x 64 ring tile: C = A W^T + bias + R, then LayerNorm of every finished row by the last-arriving column tile of its 64-row
+// block.  Launched twice on the same counters (they must be back at zero), two problems with their own gains, ragged M.
+static void test_gemm_res_ln(int op, int M, int N, int K, int groups) {
+  struct G { std::vector<uint16_t> A, W; std::vector<float> bias, R, gain, beta; };
+  std::vector<G> g(groups);
+  std::vector<Dev<uint16_t>*> dA, dW, dY16;
+  std::vector<Dev<float>*> dB, dR, dC, dY32, dG, dBe;
+  const int mt = (M + 63) / 64;
+  Dev<unsigned> dCnt((size_t)groups * mt);
+  CK(hipMemset(dCnt.p, 0, (size_t)groups * mt * 4));
+  std::vector<GemmProb> probs(groups);
+  for (int q = 0; q < groups; ++q) {
+    G& x = g[q];
+    const int Mq = q == 0 ? M : M - 7;
+    x.A.resize((size_t)M * K); x.W.resize((size_t)N * K); x.bias.resize(N); x.R.resize((size_t)M * N); x.gain.resize(N); x.beta.resize(N);
+    for (auto& v : x.A) v = to_op(frand(), op);
+    for (auto& v : x.W) v = to_op(frand(0.05f), op);
+    for (auto& v : x.bias) v = frand(0.5f);
+    for (auto& v : x.R) v = frand(2.f);
+    for (auto& v : x.gain) v = 1.f + frand(0.3f);
+    for (auto& v : x.beta) v = frand(0.2f);
+    dA.push_back(new Dev<uint16_t>(x.A)); dW.push_back(new Dev<uint16_t>(x.W)); dB.push_back(new Dev<float>(x.bias)); dR.push_back(new Dev<float>(x.R));
+    dG.push_back(new Dev<float>(x.gain)); dBe.push_back(new Dev<float>(x.beta));
+    dC.push_back(new Dev<float>((size_t)M * N)); dY32.push_back(new Dev<float>((size_t)M * N)); dY16.push_back(new Dev<uint16_t>((size_t)M * N));
+    dY32.back()->fill(0xFF); dY16.back()->fill(0xFF);
+    GemmProb& p = probs[q];
+    memset(&p, 0, sizeof(p));
+    p.A = dA[q]->p; p.a = RowView{0, M, K}; p.W = dW[q]->p; p.bias = dB[q]->p; p.R = dR[q]->p; p.r = RowView{0, M, N};
+    p.C = dC[q]->p; p.c = RowView{0, M, N}; p.M = Mq; p.N = N; p.K = K; p.tile_cfg = 11;
+    p.ln_gain = dG[q]->p; p.ln_bias = dBe[q]->p; p.ln_eps = 1e-12f; p.ln_y32 = dY32[q]->p; p.ln_y32v = RowView{0, M, N};
+    p.ln_y16 = dY16[q]->p; p.ln_y16v = RowView{0, M, N}; p.ln_counter = dCnt.p + (size_t)q * mt;
+  }
+  int rc = launch_gemm(probs.data(), groups, EPI_RES_LN, op, 0);
+  if (!rc) rc = launch_gemm(probs.data(), groups, EPI_RES_LN, op, 0);   // the counters were left at zero
+  CK(hipDeviceSynchronize());
+  double worst = rc ? 1e30 : 0;
+  std::vector<unsigned> cnt = dCnt.get();
+  for (auto v : cnt) if (v != 0) worst = 1e30;
+  for (int q = 0; q < groups && !rc; ++q) {
+    const G& x = g[q];
+    const int Mq = probs[q].M;
+    std::vector<float> y32 = dY32[q]->get();
+    std::vector<uint16_t> y16 = dY16[q]->get();
+    std::vector<double> row(N);
+    for (int m = 0; m < Mq; ++m) {
+      double mean = 0;
+      for (int n = 0; n < N; ++n) {
+        double acc = x.bias[n] + x.R[(size_t)m * N + n];
+        for (int k = 0; k < K; ++k) acc += (double)from_op(x.A[(size_t)m * K + k], op) * from_op(x.W[(size_t)n * K + k], op);
+        row[n] = acc; mean += acc;
+      }
+      mean /= N;
+      double var = 0;
+      for (int n = 0; n < N; ++n) var += (row[n] - mean) * (row[n] - mean);
+      const double rstd = 1.0 / sqrt(var / N + 1e-12);
+      for (int n = 0; n < N; ++n) {
+        const double want = (row[n] - mean) * rstd * x.gain[n] + x.beta[n];
+        worst = std::max(worst, fabs(y32[(size_t)m * N + n] - want) / (1 + fabs(want)));
+        worst = std::max(worst, 0.1 * fabs(from_op(y16[(size_t)m * N + n], op) - want) / (1 + fabs(want)));   // the 16-bit copy at a 10 x bar
+      }
+    }
+  }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm residual + LayerNorm in one launch %s M%d N%d K%d groups%d", op == OP_F16 ? "f16" : "bf16", M, N, K, groups);
+  report(name, worst, op == OP_F16 ? 5e-4 : 4e-3);
+  for (auto p : dA) delete p; for (auto p : dW) delete p; for (auto p : dY16) delete p;
+  for (auto p : dB) delete p; for (auto p : dR) delete p; for (auto p : dC) delete p; for (auto p : dY32) delete p; for (auto p : dG) delete p; for (auto p : dBe) delete p;
+}
+
 // n_mask: N not a multiple of the tile, plain [M][N] output rows; columns past N are neither read (bias, residual) nor stored
 static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K);
@@ -1077,6 +1146,11 @@ int main(int argc, char** argv) {
   test_gemm(10, EPI_OP, OP_F16, 200, 96, 448, true);
   test_gemm(10, EPI_F32, OP_BF16, 64, 288, 64, false);
   test_gemm(10, EPI_GELU_OP, OP_F16, 70, 96, 384, false);
+  test_gemm_res_ln(OP_F16, 2048, 768, 768, 1);
+  test_gemm_res_ln(OP_F16, 1024 - 30, 768, 3072, 2);
+  test_gemm_res_ln(OP_BF16, 200, 768, 128, 1);
+  test_gemm_res_ln(OP_F16, 333, 768, 256, 2);
+  test_gemm_res_ln(OP_F16, 70, 768, 64, 1);
   // an odd number of K steps takes the loader-wave 256 x 256 kernel (8 compute + 4 loader waves)
   test_gemm(2, EPI_GELU_OP, OP_F16, 600, 512, 1344, false);   // GELU epilogue, pre-activations out to |x| ~ 6
   test_gemm(2, EPI_RES_OP, OP_F16, 2 * 256 + 37, 512, 192, true);
