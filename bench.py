@@ -59,8 +59,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="clip32x32", choices=["clip32x32", "ref"],
-                    help="clip32x32: Kv=8224 video / 496 audio tokens per clip (headline); ref: the reference's one-frame items (257 / 256)")
+    ap.add_argument("--workload", default="clip32x32", choices=["clip32x32", "ref", "finetune"],
+                    help="clip32x32: Kv=8224 video / 496 audio tokens per clip (headline); ref: the reference's one-frame items (257 / 256); "
+                         "finetune: BASELINE config 5 (Q-Former fwd + bwd + optimizer step, bf16, B = 1 x T = 20 per GPU; tools/bench_finetune.py's line)")
     ap.add_argument("--clips", type=int, default=32, help="clips per GPU")
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--cpu-clips", type=int, default=-1, help="clips in the CPU-baseline sample (0 = skip, -1 = auto)")
@@ -78,6 +79,9 @@ def parse():
 
 def main():
     args = parse()
+    if args.workload == "finetune":     # BASELINE config 5 has its own step; same launch contract (one process per GPU, rank 0 prints one JSON line)
+        from tools import bench_finetune
+        return bench_finetune.main(["--steps", str(args.steps), "--warmup", str(args.warmup), "--dtype", "bf16" if args.dtype == "f16" else args.dtype])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -219,6 +219,14 @@ size_t mra_qformer_grad_bytes(mra_qformer* h);
 int32_t mra_qformer_load_flat(mra_qformer* h, const float* master, size_t master_bytes, void* stream);
 int mra_qformer_grad_offset(mra_qformer* h, const char* name, size_t* offset_bytes, int64_t* numel);
 int mra_qformer_enable_training(mra_qformer* h, void* stream);
+/* The optimizer step of BASELINE config 5 in ONE pass over the flat buffers (replaces, on the hot path, torch.optim.Adam's
+ * multi_tensor_apply + mra_qformer_load_flat + the transposed-copy rebuild; caller: utils/trainer.py:137-140 `scaler.step(optimizer)`):
+ * torch.optim.Adam's arithmetic (L2 weight decay added to the gradient, bias correction from `step` >= 1) on master / grad / exp_avg /
+ * exp_avg_sq -- four fp32 buffers of mra_qformer_grad_bytes() in the gradient buffer's layout -- and, from the same registers, every device
+ * copy the update makes stale: the operand-dtype weights, their transposed training copies, fp32 biases / LayerNorms / embeddings / query
+ * tokens.  zero_grad != 0 clears the gradient buffer on the way.  ~30 B per parameter of HBM traffic instead of ~50. */
+int mra_qformer_adam_step(mra_qformer* h, float* master, float* grad, float* exp_avg, float* exp_avg_sq, size_t bytes, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream);
 size_t mra_qformer_train_workspace_bytes(mra_qformer* h, int32_t items, int32_t L, int32_t kv);
 int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const int64_t* attention_mask, const void* enc,
                               int32_t items, int32_t L, int32_t kv, float* out_query, float* out_cls, void* workspace,

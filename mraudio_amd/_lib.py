@@ -68,6 +68,8 @@ PROTOTYPES = {
     "mra_qformer_load_flat": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mra_qformer_grad_offset": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "mra_qformer_enable_training": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mra_qformer_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "mra_qformer_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "mra_qformer_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

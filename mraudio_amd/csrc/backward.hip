@@ -549,6 +549,114 @@ __global__ void __launch_bounds__(256) transpose16_batch_kernel(const TrJob* job
     if (bx + r < j.C && by + tx < j.R) dst[(long long)(bx + r) * j.R + by + tx] = tile[tx][r];
 }
 
+__device__ __forceinline__ f32x4 adam_update(f32x4& p, f32x4& g, f32x4& m, f32x4& v, const AdamScalars& sc) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ge = g[e] + sc.weight_decay * p[e];
+    m[e] = sc.beta1 * m[e] + (1.f - sc.beta1) * ge;
+    v[e] = sc.beta2 * v[e] + (1.f - sc.beta2) * ge * ge;
+    p[e] -= sc.step_size * m[e] / (sqrtf(v[e]) * sc.inv_sqrt_bc2 + sc.eps);
+  }
+  return p;
+}
+
+// matrices with a transposed training copy: one 64 x 256 tile per workgroup (R a multiple of 64, C of 256): 1 KiB contiguous per row and array
+// (64 x 64 tiles -- 256-byte runs over nine streams -- ran the pass at 3.5 TB/s), four 16-row steps with 16 loads per thread in flight
+template <typename T>
+__global__ void __launch_bounds__(256) adam_mat_kernel(float* master, float* grad, float* mom, float* var, const AdamMatJob* jobs, int njobs, AdamScalars sc) {
+  __shared__ T tile[64][264];
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;                 // last job whose tile_begin <= b (workgroup-uniform binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const AdamMatJob j = jobs[lo];
+  const int local = b - j.tile_begin;
+  const int bx = (local % j.tiles_x) * 256, by = (local / j.tiles_x) * 64;
+  const int t = threadIdx.x, c4 = (t & 63) * 4, r0 = t >> 6;   // a wave = one 1 KiB row piece
+  T* dst = (T*)j.dst;
+#pragma unroll 1
+  for (int step = 0; step < 4; ++step) {
+    f32x4 p[4], g[4], m[4], v[4];
+    long long o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = step * 16 + it * 4 + r0;
+      o[it] = (long long)j.off + (long long)(by + r) * j.C + bx + c4;
+      p[it] = *reinterpret_cast<const f32x4*>(master + o[it]);
+      g[it] = *reinterpret_cast<const f32x4*>(grad + o[it]);
+      m[it] = *reinterpret_cast<const f32x4*>(mom + o[it]);
+      v[it] = *reinterpret_cast<const f32x4*>(var + o[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = step * 16 + it * 4 + r0;
+      adam_update(p[it], g[it], m[it], v[it], sc);
+      *reinterpret_cast<f32x4*>(master + o[it]) = p[it];
+      *reinterpret_cast<f32x4*>(mom + o[it]) = m[it];
+      *reinterpret_cast<f32x4*>(var + o[it]) = v[it];
+      if (sc.zero_grad) *reinterpret_cast<f32x4*>(grad + o[it]) = f32x4{0.f, 0.f, 0.f, 0.f};
+      typename Vec4<T>::type q;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = from_f32<T>(p[it][k]);
+      *reinterpret_cast<typename Vec4<T>::type*>(&tile[r][c4]) = q;
+      *reinterpret_cast<typename Vec4<T>::type*>(dst + (o[it] - (long long)j.off)) = q;
+    }
+  }
+  __syncthreads();
+  // transposed copy: 256 rows (source columns) x 64 elements = 128 B each; thread: 4 source rows x one column -> 8 bytes
+  T* dstT = (T*)j.dstT;
+  const int r4 = (t & 15) * 4;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int c = it * 16 + (t >> 4);
+    typename Vec4<T>::type q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = tile[r4 + k][c];
+    *reinterpret_cast<typename Vec4<T>::type*>(dstT + (long long)(bx + c) * j.ldT + by + r4) = q;
+  }
+}
+
+// every other parameter: the segment table of mra_qformer_load_flat (dst in its stored dtype)
+__global__ void __launch_bounds__(256) adam_flat_kernel(float* master, float* grad, float* mom, float* var, const FlatSeg* segs, AdamScalars sc) {
+  const FlatSeg sg = segs[blockIdx.x];
+  for (int i0 = threadIdx.x * 4; i0 < sg.n; i0 += 4096) {   // four float4 per array in flight per thread
+    f32x4 p[4], g[4], m[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * 1024, sg.n - 4);           // clamped: a tail piece is loaded twice, stored once
+      const long long o = (long long)sg.src_off + i;
+      p[u] = *reinterpret_cast<const f32x4*>(master + o); g[u] = *reinterpret_cast<const f32x4*>(grad + o);
+      m[u] = *reinterpret_cast<const f32x4*>(mom + o); v[u] = *reinterpret_cast<const f32x4*>(var + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      if (i >= sg.n) break;
+      const long long o = (long long)sg.src_off + i;
+      adam_update(p[u], g[u], m[u], v[u], sc);
+      *reinterpret_cast<f32x4*>(master + o) = p[u];
+      *reinterpret_cast<f32x4*>(mom + o) = m[u];
+      *reinterpret_cast<f32x4*>(var + o) = v[u];
+      if (sc.zero_grad) *reinterpret_cast<f32x4*>(grad + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sg.dtype == 0) {
+        *reinterpret_cast<f32x4*>((float*)sg.dst + i) = p[u];
+      } else if (sg.dtype == 1) {
+        typename Vec4<f16>::type q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (f16)p[u][k];
+        *reinterpret_cast<typename Vec4<f16>::type*>((f16*)sg.dst + i) = q;
+      } else {
+        typename Vec4<bf16>::type q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (bf16)p[u][k];
+        *reinterpret_cast<typename Vec4<bf16>::type*>((bf16*)sg.dst + i) = q;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) axpy_kernel(const float* x, float* y, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4), b = *reinterpret_cast<f32x4*>(y + i * 4);
@@ -641,6 +749,20 @@ int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, h
   const dim3 grid((C + 31) / 32, (R + 31) / 32), block(256);
   if (op_dtype == OP_F16) hipLaunchKernelGGL(transpose16_kernel<f16>, grid, block, 0, stream, (const f16*)src, (f16*)dst, R, C);
   else hipLaunchKernelGGL(transpose16_kernel<bf16>, grid, block, 0, stream, (const bf16*)src, (bf16*)dst, R, C);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_adam_mats(float* master, float* grad, float* m, float* v, const AdamMatJob* jobs_dev, int njobs, int total_tiles, AdamScalars sc, int op_dtype,
+                     hipStream_t stream) {
+  if (njobs <= 0 || total_tiles <= 0) return 0;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(adam_mat_kernel<f16>, dim3(total_tiles), dim3(256), 0, stream, master, grad, m, v, jobs_dev, njobs, sc);
+  else hipLaunchKernelGGL(adam_mat_kernel<bf16>, dim3(total_tiles), dim3(256), 0, stream, master, grad, m, v, jobs_dev, njobs, sc);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_adam_flat(float* master, float* grad, float* m, float* v, const FlatSeg* segs, int nseg, AdamScalars sc, hipStream_t stream) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(nseg), dim3(256), 0, stream, master, grad, m, v, segs, sc);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -201,6 +201,16 @@ int launch_transpose16(const void* src, void* dst, int R, int C, int op_dtype, h
 struct TrJob { const void* src; void* dst; int R, C, tile_begin, tiles_x; };
 int launch_transpose16_batch(const TrJob* jobs_dev, int njobs, int total_tiles, int op_dtype, hipStream_t stream);
 int launch_add_f32(const float* x, float* y, long long n, hipStream_t stream);  // y += x
+struct FlatSeg;
+// Fused optimizer pass of the training step (backward.hip): torch.optim.Adam's update on the flat fp32 master / gradient / moment buffers AND
+// the refresh of the device weights it makes stale, in one read of each: per element  g += wd p;  m = b1 m + (1 - b1) g;
+// v = b2 v + (1 - b2) g^2;  p -= step_size m / (sqrt(v) inv_sqrt_bc2 + eps);  then p goes out in the stored dtype (and, for the matrices
+// with a transposed training copy, transposed as well through a 64 x 64 LDS tile); zero_grad clears g on the way.
+struct AdamScalars { float beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2; int zero_grad; };
+struct AdamMatJob { unsigned long long off; void* dst; void* dstT; int R, C, ldT, tile_begin, tiles_x; };   // master offset (elements); dstT[c * ldT + r]
+int launch_adam_mats(float* master, float* grad, float* m, float* v, const AdamMatJob* jobs_dev, int njobs, int total_tiles, AdamScalars sc, int op_dtype,
+                     hipStream_t stream);
+int launch_adam_flat(float* master, float* grad, float* m, float* v, const FlatSeg* segs, int nseg, AdamScalars sc, hipStream_t stream);
 
 // ---- folded cross-attention helpers (fold.hip) ------------------------------------------------------
 // P[row][0..kv) = softmax(scale * S[row][0..kv)) in the operand dtype, P[row][kv..kvp) = 0

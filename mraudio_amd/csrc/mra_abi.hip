@@ -324,6 +324,9 @@ void mra_qformer_destroy(mra_qformer* h) {
   if (h->arena_p) (void)hipFree(h->arena_p);
   if (h->flat_segs) (void)hipFree(h->flat_segs);
   if (h->tr_jobs) (void)hipFree(h->tr_jobs);
+  if (h->adam_jobs) (void)hipFree(h->adam_jobs);
+  if (h->adam_segs) (void)hipFree(h->adam_segs);
+  if (h->c32_segs) (void)hipFree(h->c32_segs);
   for (auto& e : h->wg_ev) if (e) (void)hipEventDestroy(e);
   if (h->wg_stream) (void)hipStreamDestroy(h->wg_stream);
   delete h;

@@ -120,6 +120,14 @@ struct mra_qformer {
   int n_tr_jobs = 0, n_tr_tiles = 0;
   hipStream_t wg_stream = nullptr;                // side stream of the weight-gradient GEMMs (mra_qformer_backward)
   hipEvent_t wg_ev[32] = {};                      // ring of fork / done events between the caller's stream and wg_stream
+  // fused optimizer pass (mra_qformer_adam_step): matrices with a transposed training copy as 64 x 64 tile jobs, every other bert.* parameter
+  // (and the query tokens) as linear segments, the f32 copies of the score-chain weights as a third table; built by mra_qformer_enable_training
+  mra::AdamMatJob* adam_jobs = nullptr;
+  int n_adam_jobs = 0, n_adam_tiles = 0;
+  mra::FlatSeg* adam_segs = nullptr;
+  int n_adam_segs = 0;
+  mra::FlatSeg* c32_segs = nullptr;
+  int n_c32_segs = 0;
   size_t grad_bytes = 0;
   mra::FlatSeg* flat_segs = nullptr;  // device table behind mra_qformer_load_flat (bert.* parameters)
   int n_flat_segs = 0;

@@ -10,6 +10,8 @@
 // (utils/trainer.py:31,137) needs.  Data-gradient GEMMs reuse the forward GEMM kernels on transposed
 // weight copies (built by mra_qformer_enable_training, refreshed after every weight upload); weight
 // gradients use gemm_tn.hip; LayerNorm / GELU / attention / embedding gradients backward.hip.
+#include <cmath>
+
 #include "mra_handle.h"
 
 using namespace mra;
@@ -190,6 +192,84 @@ int mra_qformer_grad_offset(mra_qformer* h, const char* name, size_t* offset_byt
   return MRA_OK;
 }
 
+namespace {
+// tables of the fused optimizer pass (see mra_handle.h)
+int build_adam_tables(mra_qformer* h) {
+  if (h->adam_jobs) return 0;
+  const mra_cfg& c = h->cfg;
+  const int H = c.hidden, I = c.inter;
+  std::vector<AdamMatJob> jobs;
+  std::map<std::string, bool> in_mats;
+  int tiles = 0;
+  auto add = [&](const std::string& name, void* dstT, int R, int C, int ldT) {
+    const Param& pr = h->params.at(name);
+    jobs.push_back(AdamMatJob{(unsigned long long)(pr.goff / 4), pr.ptr, dstT, R, C, ldT, tiles, C / 256});
+    tiles += (R / 64) * (C / 256);
+    in_mats[name] = true;
+  };
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& L = h->layers[i];
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+    const char* names[3] = {"query", "key", "value"};
+    for (int j = 0; j < 3; ++j) add(p + "attention.self." + names[j] + ".weight", (char*)L.wqkvT + (size_t)j * H * 2, H, H, 3 * H);
+    add(p + "attention.output.dense.weight", L.woT, H, H, H);
+    if (L.cross_index >= 0) {
+      add(p + "crossattention.self.query.weight", L.wcqT, H, H, H);
+      add(p + "crossattention.output.dense.weight", L.wcoT, H, H, H);
+    }
+    add(p + "intermediate_query.dense.weight", L.wiqT, I, H, I);
+    add(p + "output_query.dense.weight", L.woqT, H, I, H);
+    add(p + "intermediate.dense.weight", L.witT, I, H, I);
+    add(p + "output.dense.weight", L.wotT, H, I, H);
+  }
+  std::vector<FlatSeg> segs, c32;
+  for (auto& kv : h->params) {
+    const Param& pr = kv.second;
+    const bool bert = kv.first.rfind("bert.", 0) == 0;
+    if (!bert && kv.first != "query_tokens") continue;
+    if (pr.copy32)
+      for (long long o = 0; o < pr.numel; o += FLAT_SEG)
+        c32.push_back(FlatSeg{(unsigned long long)(pr.goff / 4 + o), (char*)(pr.copy32 + o), (int)std::min<long long>(FLAT_SEG, pr.numel - o), MRA_F32});
+    if (in_mats.count(kv.first)) continue;
+    const size_t esz = pr.dtype == MRA_F32 ? 4 : 2;
+    for (long long o = 0; o < pr.numel; o += FLAT_SEG)
+      segs.push_back(FlatSeg{(unsigned long long)(pr.goff / 4 + o), (char*)pr.ptr + o * esz, (int)std::min<long long>(FLAT_SEG, pr.numel - o), pr.dtype});
+  }
+  auto up = [&](const void* src, size_t bytes, void** dst) {
+    if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return -3;
+    return bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess ? -4 : 0;
+  };
+  int rc = up(jobs.data(), jobs.size() * sizeof(AdamMatJob), (void**)&h->adam_jobs);
+  if (!rc) rc = up(segs.data(), segs.size() * sizeof(FlatSeg), (void**)&h->adam_segs);
+  if (!rc) rc = up(c32.data(), c32.size() * sizeof(FlatSeg), (void**)&h->c32_segs);
+  h->n_adam_jobs = (int)jobs.size(); h->n_adam_tiles = tiles; h->n_adam_segs = (int)segs.size(); h->n_c32_segs = (int)c32.size();
+  return rc;
+}
+}  // namespace
+
+int mra_qformer_adam_step(mra_qformer* h, float* master, float* grad, float* exp_avg, float* exp_avg_sq, size_t bytes, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream_) {
+  if (!h || !master || !grad || !exp_avg || !exp_avg_sq) return fail(MRA_EINVAL, "null argument");
+  if (!h->arena_t || !h->adam_jobs) return fail(MRA_ESTATE, "call mra_qformer_enable_training first");
+  if (bytes < h->grad_bytes) return fail(MRA_EINVAL, "buffers smaller than mra_qformer_grad_bytes()");
+  if (((size_t)master | (size_t)grad | (size_t)exp_avg | (size_t)exp_avg_sq) & 15) return fail(MRA_EINVAL, "buffers must be 16-byte aligned");
+  if (step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return fail(MRA_EINVAL, "bad Adam hyper-parameters");
+  if (h->cfg.hidden % 256 || h->cfg.inter % 256) return fail(MRA_EINVAL, "hidden / inter must be multiples of 256");
+  hipStream_t st = as_stream(stream_);
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  AdamScalars sc{beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)(1.0 / std::sqrt(bc2)), zero_grad ? 1 : 0};
+  int rc = launch_adam_mats(master, grad, exp_avg, exp_avg_sq, h->adam_jobs, h->n_adam_jobs, h->n_adam_tiles, sc, h->op(), st);
+  if (!rc) rc = launch_adam_flat(master, grad, exp_avg, exp_avg_sq, h->adam_segs, h->n_adam_segs, sc, st);
+  if (!rc) rc = launch_convert_flat(master, h->c32_segs, h->n_c32_segs, st);
+  if (rc) return chk(rc, "fused Adam pass");
+  for (auto& kv : h->params)
+    if (kv.first.rfind("bert.", 0) == 0) kv.second.loaded = true;
+  h->transposes_stale = false;   // the pass wrote the transposed copies too
+  h->fold_stale = true;
+  h->precise_stale = true;
+  return MRA_OK;
+}
+
 int mra_qformer_enable_training(mra_qformer* h, void* stream) {
   if (!h) return fail(MRA_EINVAL, "null handle");
   if (!h->arena_t) {
@@ -203,6 +283,7 @@ int mra_qformer_enable_training(mra_qformer* h, void* stream) {
     HIP_TRY(hipStreamCreateWithFlags(&h->wg_stream, hipStreamNonBlocking));
     for (auto& e : h->wg_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  if (build_adam_tables(h)) return fail(MRA_ENOMEM, "tables of the fused optimizer pass");
   if (h->transposes_stale) return chk(refresh_transposes(h, as_stream(stream)), "weight transposes");
   return MRA_OK;
 }

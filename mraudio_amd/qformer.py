@@ -465,6 +465,26 @@ class QFormer(nn.Module):
         return fp
 
 
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, zero_grad: bool = True) -> None:
+        """One ``torch.optim.Adam`` step on this Q-Former's flat master / gradient buffers on the HIP extension
+        (``mra_qformer_adam_step``): update, refresh of every device weight copy (operand dtype + transposed training copies) and, with
+        ``zero_grad``, the clearing of the gradient buffer in ONE pass.  The moments live in two flat fp32 buffers created here."""
+        self.enable_training()
+        if getattr(self, "_exp_avg", None) is None:
+            self._exp_avg = torch.zeros_like(self._master_flat)
+            self._exp_avg_sq = torch.zeros_like(self._master_flat)
+            self._adam_t = 0
+        self._bind_master()
+        self._adam_t += 1
+        with torch.cuda.device(self._device):
+            check(lib().mra_qformer_adam_step(self._handle, ptr(self._master_flat), ptr(self._grad_flat), ptr(self._exp_avg), ptr(self._exp_avg_sq),
+                                              self._master_flat.numel() * 4, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                              float(weight_decay), int(self._adam_t), int(bool(zero_grad)), current_stream()), "mra_qformer_adam_step")
+        # the pass refreshed the device copies itself: nothing is stale (the version counters were not bumped either)
+        self._param_version = sum(p._version for p in self.bert.parameters())
+        self._dirty = False
+        self._grads_zeroed = bool(zero_grad)
+
     def _run_backward(self, input_ids, attention_mask, enc, N, L, Kv, d_q, d_c) -> None:
         # optimizer.zero_grad(set_to_none=True) drops the views: start from a clean buffer in that case
         probe = self.bert.embeddings.LayerNorm.weight

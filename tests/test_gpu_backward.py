@@ -203,3 +203,88 @@ def test_flat_parameter_update_equals_per_tensor_update(dev):
     # gradients): the flat and the per-tensor update must agree to that noise level, far below one update (~1e-3)
     assert (w0 - w1).abs().max().item() < 1e-5 and (q0 - q1).abs().max().item() < 5e-5
     assert abs(l0 - l1) < 1e-3
+
+
+def test_fused_adam_step_equals_torch_adam_on_the_same_gradients(dev):
+    """``mra_qformer_adam_step`` (update + device-copy refresh + gradient clearing in one pass) against ``torch.optim.Adam`` stepping a
+    copy of the same master buffer with the same gradients: three steps, weight decay on, bias correction exercised; then the DEVICE
+    copies really are the updated weights (a forward through the handle equals a forward after re-uploading the master values)."""
+    qf, cfg, ocfg, w = _setup(dev, 768, 2)
+    qf.enable_training()
+    n = qf._master_flat.numel()
+    ref_p = torch.nn.Parameter(qf._master_flat.detach().clone())
+    opt = torch.optim.Adam([ref_p], lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.02)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for step in range(3):
+        grad = torch.randn(n, generator=g, device=dev) * (0.5 ** step)
+        qf._grad_flat.copy_(grad)
+        ref_p.grad = grad.clone()
+        opt.step()
+        qf.adam_step(3e-3, (0.9, 0.99), 1e-8, 0.02, zero_grad=True)
+        for name in ("bert.encoder.layer.3.output.dense.weight", "bert.embeddings.word_embeddings.weight", "bert.encoder.layer.0.attention.self.key.bias", "query_tokens"):
+            assert float(qf.grad_of(name).abs().max()) == 0.0, name               # every parameter's gradient is cleared on the way
+        for name in ("bert.encoder.layer.3.output.dense.weight", "bert.embeddings.word_embeddings.weight", "bert.encoder.layer.11.output_query.LayerNorm.bias", "query_tokens"):
+            off, numel = qf._slice_of(name)
+            d = (qf._master_flat[off: off + numel] - ref_p.detach()[off: off + numel]).abs().max().item()
+            assert d < 2e-6, (step, name, d)                                    # same arithmetic, fp32 rounding order only
+    # the device copies follow: forward through the handle == forward of a fresh handle loaded with the master values
+    ids, tmask, att, feats = make_inputs(ocfg, 3, 5, 40, 9, False)
+    enc = O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]).half().to(dev)
+    z_fused = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"].clone()
+    q_train, _ = qf.forward_train(ids.to(dev), att.to(dev), enc, want_cls=False)   # uses the transposed copies' siblings (same weights)
+    qf._dirty = True                                                             # force the ordinary re-upload path (mra_qformer_load_flat)
+    z_reload = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_query=True)["query"]
+    assert torch.equal(z_fused, z_reload)
+    assert (q_train.detach() - z_fused).abs().max().item() < 2e-2
+
+
+def test_training_loss_equals_the_oracle_bce_and_one_fused_step_follows_torch_adam(dev):
+    """Row N1: ``model(samples)["loss"]`` of a Charades-STA-shaped batch equals the build-defined objective evaluated on
+    the ORACLE's logits (binary cross-entropy of sigmoid(20 x fused logit) against clip membership, 1e-3), and one ``FusedQFormerAdam``
+    step moves the parameters as ``torch.optim.Adam`` does on the same (HIP-computed) gradients."""
+    from mraudio_amd.models.xinstructblip import ENC_WIDTH, XInstructBLIP
+    from mraudio_amd.utils.optim import FusedQFormerAdam
+
+    model = XInstructBLIP(seed=3, perturb=True, device=dev)
+    model.enable_qformer_training()
+    g = torch.Generator().manual_seed(2)
+    T = 20
+    samples = {"video_embeds": torch.randn(1, T, 257, 1408, generator=g), "audio_embeds": torch.randn(1, T, 256, 768, generator=g),
+               "text_input": ["Query: a person opens the door.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
+               "text_output": ["[[6, 12]]"], "timestamps": [list(range(0, 2 * T, 2))], "duration": [2 * T]}
+    loss = model(samples)["loss"]
+    # the oracle on the same inputs
+    text = model.tokenizer(samples["text_input"], padding="longest", truncation=True, max_length=128, return_tensors="pt")
+    ids, tm = text.input_ids.repeat(T, 1), text.attention_mask.repeat(T, 1)
+    cfgs = {m: O.QFormerCfg(enc_width=ENC_WIDTH[m]) for m in ("video", "audio")}
+    ws = {"video": O.init_weights(cfgs["video"], seed=3, perturb=True), "audio": O.init_weights(cfgs["audio"], seed=4, perturb=True)}
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = O.encode_fuse_score(ws, cfgs, {m: samples[f"{m}_embeds"][0] for m in ("audio", "video")}, ids, tm, 1, T)
+    ts = torch.tensor(samples["timestamps"][0], dtype=torch.float32)
+    target = ((ts >= 6) & (ts <= 12)).float()
+    want = torch.nn.functional.binary_cross_entropy_with_logits(ref["fused"] * 20.0, target)
+    assert abs(loss.item() - want.item()) <= 1e-3 * max(1.0, abs(want.item())), (loss.item(), want.item())
+    # one optimizer step: FusedQFormerAdam vs torch.optim.Adam on copies of the same master values and gradients
+    loss.backward()
+    refs = []
+    for m in model.modalities:
+        qf = getattr(model, f"{m}_Qformer")
+        p = torch.nn.Parameter(qf._master_flat.detach().clone())
+        p.grad = qf._grad_flat.detach().clone()
+        refs.append(p)
+    ropt = torch.optim.Adam(refs, lr=1e-4)
+    ropt.step()
+    opt = FusedQFormerAdam(model, lr=1e-4)
+    opt.step()
+    for m, p in zip(model.modalities, refs):
+        qf = getattr(model, f"{m}_Qformer")
+        moved = (p.detach() - qf._master_flat).abs().max().item()
+        assert moved < 1e-7 + 2e-2 * 1e-4, (m, moved)          # 2e-2 of one update (lr = 1e-4 per element at most)
+    opt.zero_grad()
+    # the step refreshed the device copies itself: the next forward equals one after a forced re-upload of the master values
+    loss2 = model(samples)["loss"]
+    for m in model.modalities:
+        getattr(model, f"{m}_Qformer")._dirty = True
+    loss3 = model(samples)["loss"]
+    assert torch.isfinite(loss2) and abs(loss2.item() - loss3.item()) < 1e-6 and abs(loss2.item() - loss.item()) > 1e-6

@@ -400,3 +400,42 @@ def test_folded_path_on_a_small_configuration(dev):
     assert (got - ref).abs().max().item() < 5e-3
     h = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(5, -1, -1), O.modality_layernorm(feats, w["ln.weight"], w["ln.bias"]))
     assert (got.cpu() - h[:, :32]).abs().max().item() < Z_ATOL
+
+
+def test_layer_chain_on_the_ring_tiles_and_with_the_layernorm_inside_the_launch(video, dev):
+    """Round 3: at ~2 k rows the chain's GEMMs run on ``gemm_ring_kernel``'s exact-fit tiles (``chain_ring`` mask, default 7: QKV 144 x 128,
+    FFN-up 192 x 128, residual projections 96 x 64); bit 3 adds the LayerNorm inside the residual projection's launch (EPI_RES_LN, opt-in).
+    32 items x (32 + 32) rows = the bench's chain shape; Kv = 257 (K/V-cache path).  Every mask must reproduce the round-2 tiles (mask 0) to
+    fp32 summation order and meet the oracle bars; the launch counters say the ring kernels really ran."""
+    from mraudio_amd import _lib as L
+
+    qf, cfg, w = video
+    n, Lt, kv = 32, 32, 257
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(n, kv, 1408, generator=g)
+    ids = torch.randint(1000, 30000, (n, Lt), generator=g)
+    att = torch.ones(n, 32 + Lt, dtype=torch.long)
+    att[3, 32 + 20:] = 0                       # one ragged prompt
+    enc = qf.modality_ln(feats.to(dev))
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = O.qformer_forward(w, oracle_cfg(cfg), ids, att, w["query_tokens"].expand(n, -1, -1), enc.float().cpu())
+    GF_RING = (11, 12, 13)                      # GemmFamily: ring 144 x 128, 192 x 128, 96 x 64
+    outs = {}
+    for mask in (0, 7, 15):
+        qf.set_option("chain_ring", mask)
+        before = [sum(L.gemm_launches(f, e) for e in (0, 1, 2, 9)) for f in GF_RING]
+        res = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_full=True)
+        torch.cuda.synchronize()
+        after = [sum(L.gemm_launches(f, e) for e in (0, 1, 2, 9)) for f in GF_RING]
+        ran = [a - b for a, b in zip(after, before)]
+        # QKV and FFN-up once per layer; the 96 x 64 tile: attention-output + FFN-down per layer, with the LayerNorm inside also the 6 cross-attention outputs
+        assert ran == {0: [0, 0, 0], 7: [12, 12, 24], 15: [12, 12, 30]}[mask], (mask, ran)
+        if mask == 15:
+            assert L.gemm_launches(13, 9) > 0                                       # EPI_RES_LN launches (all but the last layer's down-projection)
+        outs[mask] = res["full"].cpu()
+        assert torch.isfinite(outs[mask]).all()
+        assert (outs[mask] - ref)[att.bool()].abs().max().item() < Z_ATOL, mask
+    qf.set_option("chain_ring", 7)
+    valid = att.bool()
+    assert (outs[7] - outs[0])[valid].abs().max().item() < 2e-3 and (outs[15] - outs[7])[valid].abs().max().item() < 1e-4

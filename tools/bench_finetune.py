@@ -17,18 +17,20 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--per-tensor-adam", action="store_true", help="A/B: ~800 per-tensor parameters instead of the two flat ones")
-    args = ap.parse_args()
+    ap.add_argument("--fused-adam", action="store_true", help="A/B: the one-pass mra_qformer_adam_step (update + device-copy refresh + transposed copies + gradient "
+                                                              "clearing) instead of torch.optim.Adam(fused=True) on the flat parameters; measured r03f: 17.6 vs 17.3 ms per step")
+    args = ap.parse_args(argv)
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=dev)
     from mraudio_amd.models.xinstructblip import XInstructBLIP
 
@@ -40,9 +42,13 @@ def main():
                "text_output": ["[[6, 12]]"], "timestamps": [list(range(0, 40, 2))], "duration": [40]}
     if args.per_tensor_adam:
         params = [p for d in model.get_optimizer_params(0.05) for p in d["params"] if p.shape[0] != 30523]
-    else:
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    elif not args.fused_adam:
         params = model.flat_optimizer_params()       # one flat fp32 parameter per Q-Former
-    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    else:
+        from mraudio_amd.utils.optim import FusedQFormerAdam
+        opt = FusedQFormerAdam(model, lr=1e-4)       # update + device-copy refresh + gradient clearing in one pass per Q-Former
     t = {"fwd": 0.0, "bwd": 0.0, "allreduce": 0.0, "adam": 0.0}
 
     def tick():
@@ -70,6 +76,7 @@ def main():
         print(json.dumps({"config": "BASELINE config 5: Q-Former fwd+bwd finetune step, B=1 x T=20 per GPU, both modalities", "n_gpus": world,
                           "dtype": args.dtype, "steps": args.steps, "ms_per_step": round(total / args.steps * 1e3, 2),
                           "steps_per_s_per_gpu": round(args.steps / total, 2), "clips_per_s": round(20 * world * args.steps / total, 1),
+                          "optimizer": "torch.optim.Adam per tensor" if args.per_tensor_adam else ("mra_qformer_adam_step (FusedQFormerAdam)" if args.fused_adam else "torch.optim.Adam(fused) on flat parameters"),
                           "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t.items()}, "loss": round(loss.item(), 4)}))
     if world > 1:
         dist.destroy_process_group()
