@@ -1169,6 +1169,16 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
 
   // ---- epilogue: the groups exchange halves of their partial sums (fragment f = i * FM + j belongs to group f & 1), each finishes its
   //      half (bias, GELU, conversion) into a row-major tile in LDS, then every wave copies whole-row pieces out ----
+  // the bias pieces ride the round trip of the exchange below (read next to their use they cost ~1 us of exposed latency: stamps r03g)
+  f32x4 bvs[FN];
+  {
+    const int ln = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      bvs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!RESID && P.bias) bvs[i] = *reinterpret_cast<const f32x4*>(P.bias + n0 + wn0 + i * 16 + ln);   // RES_F32 / RES_LN: bias and residual are inside group 0's accumulators
+    }
+  }
   __syncthreads();   // the ring is dead
   {
     static_assert((FN * FM) % 2 == 0, "fragments split evenly over the two groups");
@@ -1187,8 +1197,7 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       const int nl = wn0 + i * 16 + ln;
-      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!RESID && P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);   // RES_F32 / RES_LN: bias and residual are inside group 0's accumulators
+      const f32x4 bv = bvs[i];
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         if (((i * FM + j) & 1) != group) continue;
