@@ -1509,7 +1509,7 @@ int launch_ws_pv(const GemmArgs& a, int epi, hipStream_t stream) {   // 176 (wei
   if (a.p[0].w_ld > 0) {   // K-major weights (P . enc straight from the encoder tokens)
     if (epi != EPI_OP) return -2;
     if (a.p[0].pscale) {
-      if (a.p[0].M > 512 || a.p[0].ps_ntiles <= 0) return -1;
+      if (a.p[0].M > 384 || a.p[0].ps_ntiles <= 0) return -1;   // one row tile: the factor slice is indexed by the row inside the tile
       return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true, true>, a, 768, lds + 4 * 2048, stream);
     }
     return launch_k(gemm_ws_kernel<T, EPI_OP, false, 176, 384, 8, true, true>, a, 768, lds, stream);
@@ -1678,7 +1678,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (epi == EPI_SOFTPART && (cfg != 4 || !p.stat_m || !p.stat_l || p.bias || (p.c.ld & 3))) return -1;
     if (p.w_ld && (cfg != 4 || epi != EPI_OP || (p.w_ld & 7) || p.k_rows <= 0 || p.N % 176)) return -1;
     if (p.w_kwrap && (p.w_kwrap < 0 || p.w_ld || (cfg != 3 && cfg != 4) || 2 * p.w_kwrap * 64 != p.K)) return -1;   // 128 x 384 / 176 x 384 loader-wave tiles only: K = 2 passes over the weights
-    if (p.pscale && (!p.w_ld || cfg != 4 || p.M > 512 || p.ps_ntiles <= 0 || p.K > p.ps_ntiles * 176 + 4 * 176)) return -1;
+    if (p.pscale && (!p.w_ld || cfg != 4 || p.M > 384 || p.ps_ntiles <= 0 || p.K > p.ps_ntiles * 176 + 4 * 176)) return -1;   // M <= the 384-row tile (slices hold 512 rows)
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;

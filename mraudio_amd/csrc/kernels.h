@@ -84,7 +84,8 @@ struct GemmProb {
   // pscale != nullptr (176 x 384 loader-wave tile with K-major W only): the A operand is the unnormalised P~ of the split softmax; A[m][k]
   // is multiplied by pscale[((batch entry * ps_ntiles) + min(k / 176, ps_ntiles - 1)) * 512 + m] on its way into the MFMA (f16: packed
   // multiplies with the factor rounded to f16; bf16: in fp32, rounded once -- what the separate rescale pass did in HBM).  A must be
-  // ZERO from column ps_ntiles * 176 on (launch_fold_rowfactor does that).  M <= 512.
+  // ZERO from column ps_ntiles * 176 on (launch_fold_rowfactor does that).  M <= 384 (one row tile: the kernel indexes the
+  // 512-row factor slice by the row inside the tile).
   const float* pscale;
   int ps_ntiles;
   int tile_cfg;    // 0 = automatic, 1 / 2 / 3 = force the 64 / 128 / 256 tile, 4 = the 128 (weight rows) x 384 (activation

@@ -385,8 +385,22 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
   const int op = X.op;
   int evi = 0;
   auto next_event = [&]() { return h->wg_ev[evi++ % (int)(sizeof(h->wg_ev) / sizeof(h->wg_ev[0]))]; };
-  auto fork = [&]() { hipEvent_t e = next_event(); (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(h->wg_stream, e, 0); };
-  auto done = [&]() { hipEvent_t e = next_event(); (void)hipEventRecord(e, h->wg_stream); return e; };
+  // A failed record / wait would turn into an unsynchronised read of a scratch tensor or a missing join: the first HIP error is kept
+  // and reported, and EVERY exit after the first fork -- error exits included -- joins the side stream before returning (the caller
+  // may reuse or free the workspace and gradient buffers right after the call).
+  hipError_t sync_err = hipSuccess;
+  bool forked = false;
+  auto note = [&](hipError_t r) { if (r != hipSuccess && sync_err == hipSuccess) sync_err = r; };
+  auto fork = [&]() {
+    hipEvent_t e = next_event();
+    forked = true;
+    hipError_t r = hipEventRecord(e, stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent(h->wg_stream, e, 0);
+    note(r);
+  };
+  auto done = [&]() { hipEvent_t e = next_event(); note(hipEventRecord(e, h->wg_stream)); return e; };
+  auto wait_for = [&](hipEvent_t e) { note(hipStreamWaitEvent(stream, e, 0)); };
+  auto body = [&]() -> int {
   hipEvent_t ffn_done = nullptr, attn_done = nullptr;   // weight gradients of the previously processed layer
   TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
   const long long SH = (long long)S * H;
@@ -412,7 +426,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
     const char* u_t = b.u16 + (size_t)N * Q * I * 2;
     const char* f_t = b.f16 + (size_t)N * Q * I * 2;
     char* dff_t = t.dff16 + (size_t)N * Q * I * 2;
-    if (ffn_done) (void)hipStreamWaitEvent(stream, ffn_done, 0);   // dpre16 / dff16 / dpre2_16 / dqc16 are about to be rewritten
+    if (ffn_done) wait_for(ffn_done);   // dpre16 / dff16 / dpre2_16 / dqc16 are about to be rewritten
     // ---- feed-forward, query rows: out = LN(pre3), pre3 = f Woq^T + b + fq ----
     {
       LnBwdArgs a{};
@@ -476,7 +490,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
     }
     ffn_done = done();   // behind this layer's feed-forward and cross-attention weight gradients
     // ---- self-attention block: h1 = LN(pre1), pre1 = ctx Wo^T + b + hin ----
-    if (attn_done) (void)hipStreamWaitEvent(stream, attn_done, 0);   // dpre16b / dqkv16 are about to be rewritten
+    if (attn_done) wait_for(attn_done);   // dpre16b / dqkv16 are about to be rewritten
     {
       LnBwdArgs a{};
       a.dy = dh1; a.dyv = all_rows; a.x = b.pre1; a.xv = all_rows; a.gamma = W.ln1g; a.eps = c.ln_eps; a.rows = N * S;
@@ -535,7 +549,17 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
         return chk(rc, "dWkv");
     }
   }
-  (void)hipStreamWaitEvent(stream, done(), 0);   // join: what follows on `stream` sees every gradient
+  return MRA_OK;
+  };   // body
+  const int rc_body = body();
+  if (forked) {   // join: what follows on `stream` sees every gradient, and nothing on the side stream still reads the caller's buffers
+    hipEvent_t e = next_event();
+    hipError_t r = hipEventRecord(e, h->wg_stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent(stream, e, 0);
+    if (r != hipSuccess) { note(r); (void)hipStreamSynchronize(h->wg_stream); }   // last resort: a host-side join
+  }
+  if (rc_body) return rc_body;
+  if (sync_err != hipSuccess) return fail(MRA_EHIP, std::string("side-stream synchronisation of the weight gradients: ") + hipGetErrorString(sync_err));
   return MRA_OK;
 }
 
