@@ -195,6 +195,8 @@ def main():
         # formulation does for one layer (K and V projection of every token + the attention core).
         block_alg = 4.0 * n_local * kv["video"] * E * H + 4.0 * n_local * Q * kv["video"] * H
         block_exec = 4.0 * n_local * R * kv["video"] * E + 4.0 * n_local * Q * H * E
+        if args.cross_precision == "split":   # Q' as (hi | lo): the scores product walks the slab twice; the two small projections run three-fold
+            block_exec += 2.0 * n_local * R * kv["video"] * E + 4.0 * n_local * Q * H * E
         achieved = block_exec / (kv_step_ms * 1e-3) / 1e12
     else:
         block_alg = block_exec = kv_flops
@@ -209,11 +211,11 @@ def main():
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
     # PMC passes of the build in force: the in-register rescale (default) or the separate rescale pass (cross mode 5 = the r02 mid-round build)
-    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r02c_pmc_fold.json")
+    fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json" if args.cross_mode == "fold_rescale_pass" else "r03_pmc_fold.json")
     if not os.path.exists(fold_pmc):
-        fold_pmc = os.path.join(ROOT, "profiles", "r02_pmc_fold.json")
+        fold_pmc = os.path.join(ROOT, "profiles", "r02c_pmc_fold.json")
     traffic_src = "profiles/r02c_pmc_kvproj_p8.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass)" if traffic else None
-    if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and os.path.exists(fold_pmc):
+    if folded and args.workload == "clip32x32" and args.dtype == "f16" and n_local == 32 and args.cross_precision == "op" and os.path.exists(fold_pmc):
         traffic = json.load(open(fold_pmc)).get("hbm_bytes_per_block")
         traffic_src = f"profiles/{os.path.basename(fold_pmc)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, separate passes; summed over the block)"
 

@@ -1,7 +1,7 @@
 set -o pipefail
-O=gpurun_out/${1:-r02z}
+O=gpurun_out/${1:-r03z}
 mkdir -p $O
-python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log; python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 (cd tests/native && timeout -k 10 400 ./kernel_check quick > ../../$O/kernel_check.log 2>&1; tail -2 ../../$O/kernel_check.log)
 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -1 $O/bench.err
 python bench.py --workload ref --no-encode > $O/bench_ref_line.json 2>> $O/bench.err
@@ -13,5 +13,5 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-encode --cpu-clips 0 > $O/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_ft -o ft --output-format csv -- python3 tools/bench_finetune.py --steps 5 > $O/prof_ft.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_vit -o vit --output-format csv -- python3 tools/bench_vit.py --frames 256 --reps 2 > $O/prof_vit.log 2>&1
-bash tools/pmc_fold.sh r02 > $O/pmc.log 2>&1; tail -1 $O/pmc.log | cut -c1-300
+bash tools/pmc_fold.sh ${1:-r03} > $O/pmc.log 2>&1; tail -1 $O/pmc.log | cut -c1-300
 ls $O
