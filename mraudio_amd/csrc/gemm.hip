@@ -1573,6 +1573,7 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
   if (cfg == 7) {                                                        // N = 256 k + 128: full tiles + one 128 x 512 tail tile per pair of row tiles
     constexpr size_t ldst = 2 * (128 + 512) * 128;
     switch (epi) {
+      case EPI_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_OP>, a, 512, ldst, stream));   // the ViT's un-padded QKV (N = 4224)
       case EPI_RES_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream));
       case EPI_RES_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream));
       case EPI_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream));

@@ -1,4 +1,4 @@
-"""Build-time audit of the eight-phase GEMM kernels in mraudio_amd/csrc/gemm.hip (run by the Makefile before gemm.o is built).
+"""Build-time audit of the eight-phase and ring GEMM kernels in mraudio_amd/csrc/gemm.hip (run by the Makefile before gemm.o is built).
 
 ``gemm_p8_tile`` counts its own vector-memory queue: per pair of K tiles eight LDS-DMA half-tiles are issued and two counted
 ``s_waitcnt vmcnt(6)`` (``vmcnt(9)`` on the 128 x 512 tail tile) leave exactly the three youngest in flight.  That arithmetic only
@@ -112,11 +112,46 @@ def audit(name, lines):
     return errs
 
 
+def audit_ring(name, lines):
+    """gemm_ring_kernel counts its LDS-DMA queue too ((STAGES - 3) x pieces per wave stay in flight): inside its K loop no scratch access, no
+    vector-memory instruction other than the LDS-DMA, and no ``s_waitcnt vmcnt`` that is not the source's own."""
+    errs = []
+    loops = k_loops(lines)
+    if not loops:
+        errs.append("K loop not found")
+    state, cur = {}, False
+    for i, l in enumerate(lines):
+        s = l.strip()
+        if s.startswith(";;#ASMSTART"):
+            cur = True
+        elif s.startswith(";;#ASMEND"):
+            cur = False
+        state[i] = cur
+    for hdr, idx in loops:
+        ndma = 0
+        for i in idx:
+            s = lines[i].strip().split(";")[0].strip()
+            if not s or s.startswith(".") or s.endswith(":"):
+                continue
+            op = s.split()[0]
+            if op.startswith("scratch_"):
+                errs.append(f"{hdr} line {i}: scratch access inside the K loop: '{s}'")
+            elif op == "global_load_lds_dwordx4":
+                ndma += 1
+            elif op.startswith(("global_", "buffer_", "flat_")):
+                errs.append(f"{hdr} line {i}: vector-memory instruction other than the LDS-DMA inside the K loop: '{s}'")
+            elif op == "s_waitcnt" and "vmcnt" in s and not state[i]:
+                errs.append(f"{hdr} line {i}: compiler-inserted '{s}' inside the K loop")
+        if ndma == 0:
+            errs.append(f"{hdr}: no LDS-DMA inside the K loop")
+    return errs
+
+
 def main(path):
     text = open(path).read().splitlines()
     kernels, cur = {}, None
     for l in text:
-        m = re.match(r"^(_ZN3mra[^:]*gemm_p8_(?:mixed_)?kernel[^:]*):", l)
+        m = re.match(r"^(_ZN3mra[^:]*gemm_(?:p8_(?:mixed_)?|ring_)kernel[^:]*):", l)
         if m:
             cur = []
             kernels[m.group(1)] = cur
@@ -129,7 +164,7 @@ def main(path):
         return 1
     bad = 0
     for name, lines in kernels.items():
-        errs = audit(name, lines)
+        errs = audit_ring(name, lines) if "gemm_ring_kernel" in name else audit(name, lines)
         print(f"audit_gemm_p8: {name}: {'OK' if not errs else 'FAILED'}")
         for e in errs[:12]:
             print("   ", e)
