@@ -12,9 +12,11 @@
 // the N = 1408 ones as full tiles plus a 128 x 512 tail tile per pair of row tiles, GemmProb::tile_cfg 8) with bias / GELU /
 // residual fused: the residual GEMMs START their accumulators at bias + residual, so their epilogue only stores.  The fp32
 // residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
-// Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
-// per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
-// MFMA steps; the zero columns add nothing to any dot product.
+// Head dimension 88 is not a multiple of the MFMA K step: the attention core (vit_attn_kernel below) runs on 3 x 32-deep MFMA
+// steps over heads zero-extended to 96 -- the zero columns add nothing to any dot product.  Since round 3 the extension happens
+// on the core's LDS fill and Q | K | V leave the GEMM un-padded (N = 3 x 1408 = 4224 = 16 full column tiles + one 128-wide tail
+// tile per pair of row tiles on the mixed eight-phase kernel): the round-2 layout (QKV weight regrouped [q|k|v][head][96] with
+// eight zero rows per head) cost that GEMM 9 % of its flops and is kept only for geometries where 3 x dim is not 256 k + 128.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
