@@ -56,6 +56,7 @@ def main(argv=None) -> None:
     ap.add_argument("--model-path", default=None)
     ap.add_argument("--audio-encoder", default=None)
     ap.add_argument("--checkpoint", default=None, help="state dict (.pth, reference key names) with the Q-Former / LN / projection weights")
+    ap.add_argument("--partial-checkpoint", action="store_true", help="accept a checkpoint that holds only part of the parameters (e.g. the trainer's trainable-only files); what it lacks keeps the seeded init and is reported")
     ap.add_argument("--video-folder", default=None)
     ap.add_argument("--annotation-file", default=None)
     ap.add_argument("--embeds-folder", default=None, help="pre-extracted encoder outputs, <vid>.pt")
@@ -67,7 +68,7 @@ def main(argv=None) -> None:
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N seeded synthetic videos instead of a corpus")
     args = ap.parse_args(argv)
     n_frms = 60 if args.dataset == "QVH" else 20
-    model = XInstructBLIP(args.model_path, args.audio_encoder, device=args.device, checkpoint=args.checkpoint)
+    model = XInstructBLIP(args.model_path, args.audio_encoder, device=args.device, checkpoint=args.checkpoint, checkpoint_strict=not args.partial_checkpoint)
     print(f"weights: {model.weights_source}")
     if args.synthetic:
         ds = SyntheticMRDataset(args.synthetic, T=n_frms)

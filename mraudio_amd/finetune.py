@@ -47,6 +47,7 @@ def main(argv=None):
     ap.add_argument("--model-path", default=None)
     ap.add_argument("--audio-encoder", default=None)
     ap.add_argument("--checkpoint", default=None, help="initial weights: state dict (.pth, reference key names)")
+    ap.add_argument("--partial-checkpoint", action="store_true", help="accept a checkpoint that holds only part of the parameters (e.g. the trainer's trainable-only files); what it lacks keeps the seeded init and is reported")
     ap.add_argument("--video-folder", default=None)
     ap.add_argument("--train-annotation-file", default=None)
     ap.add_argument("--val-annotation-file", default=None)

@@ -117,7 +117,7 @@ class XInstructBLIP(nn.Module):
                  perturb: bool = False, op_dtype: torch.dtype = torch.float16, device=None,
                  compat_repeat: bool = True, score_alpha: float = 0.5, fuse_weights: Optional[Sequence[float]] = None,
                  process_group=None, qformer_overrides: Optional[dict] = None, overlap_modalities: bool = True,
-                 llm_hidden_size: int = 4096, checkpoint: Optional[str] = None):
+                 llm_hidden_size: int = 4096, checkpoint: Optional[str] = None, checkpoint_strict: bool = True):
         super().__init__()
         self.model_path, self.audio_path = model_path, audio_path
         self.modalities = list(modalities) if modalities is not None else ["audio", "video"]  # reference :71
@@ -174,8 +174,8 @@ class XInstructBLIP(nn.Module):
         # (``:79-194``; ``model_path`` there is the Vicuna directory, ``audio_path`` the BEATs checkpoint); offline they
         # come from ``checkpoint`` (a state dict with the reference's key names) or stay the seeded synthetic init.
         self.weights_source = f"synthetic (seed {seed})"
-        if checkpoint is not None:
-            self.load_checkpoint(checkpoint)
+        if checkpoint is not None:   # strict like the reference's load_checkpoint; checkpoint_strict=False = its load_from_pretrained (a trainer checkpoint holds trainable parameters only)
+            self.load_checkpoint(checkpoint) if checkpoint_strict else self.load_from_pretrained(checkpoint)
         elif model_path is not None or audio_path is not None:
             logging.warning("XInstructBLIP(model_path=%r, audio_path=%r): no checkpoint was given, the Q-Former / LayerNorm / "
                             "projection weights are the SYNTHETIC seeded init -- predictions are not meaningful.  Pass "

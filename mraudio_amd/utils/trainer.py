@@ -80,7 +80,8 @@ class Trainer:
                 raise NotImplementedError("only X-InstructBLIP has a trainable path in this build (VideoLLaMA is a stub)")
             from ..models.xinstructblip import XInstructBLIP
             model = XInstructBLIP(getattr(args, "model_path", None), getattr(args, "audio_encoder", None), device=self.device,
-                                  op_dtype=getattr(args, "op_dtype", torch.bfloat16), checkpoint=getattr(args, "checkpoint", None))
+                                  op_dtype=getattr(args, "op_dtype", torch.bfloat16), checkpoint=getattr(args, "checkpoint", None),
+                                  checkpoint_strict=not getattr(args, "partial_checkpoint", False))
         self.model = model
         if hasattr(model, "clip_parallel"):
             model.clip_parallel = False            # ranks see different samples

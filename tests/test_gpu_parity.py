@@ -443,3 +443,33 @@ def test_layer_chain_on_the_ring_tiles_and_with_the_layernorm_inside_the_launch(
     d70, d157 = (outs[7] - outs[0])[valid].abs().max().item(), (outs[15] - outs[7])[valid].abs().max().item()
     print('chain_ring 7 vs 0:', d70, ' 15 vs 7:', d157)
     assert d70 < 6e-3 and d157 < 6e-3
+
+
+def test_split_precision_chain_on_both_encoder_widths(video, audio, dev):
+    """``set_cross_precision("split")`` on the diffuse synthetic weights must change nothing beyond rounding (it carries MORE bits) and
+    work for both encoder widths: video (E = 1408: K-major P.enc, row factors in registers) and audio (E = 768: the 128 x 128 P.enc
+    fallback with an enc^T copy and the rescale pass), at the reference's item shape (the folded form is forced) and on a ragged prompt."""
+    for (qf, cfg, w), kv in ((video, 257), (audio, 256)):
+        ocfg = oracle_cfg(cfg)
+        n, Lt = 5, 12
+        g = torch.Generator().manual_seed(31)
+        feats = torch.randn(n, kv, cfg.enc_width, generator=g)
+        ids = torch.randint(1000, 30000, (n, Lt), generator=g)
+        att = torch.ones(n, 32 + Lt, dtype=torch.long)
+        att[2, 32 + 7:] = 0
+        enc = qf.modality_ln(feats.to(dev))
+        with torch.no_grad():
+            ref = O.qformer_forward(w, ocfg, ids, att, w["query_tokens"].expand(n, -1, -1), enc.float().cpu())
+        base = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_full=True)["full"].cpu()
+        qf.set_cross_precision("split")
+        try:
+            got = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_full=True)["full"].cpu()
+        finally:
+            qf.set_cross_precision("op")
+        valid = att.bool()
+        assert torch.isfinite(got).all()
+        e_split, e_base = (got - ref)[valid].abs().max().item(), (base - ref)[valid].abs().max().item()
+        print(f"split precision E {cfg.enc_width}: max|d| vs oracle {e_split:.2e} (operand-dtype chain {e_base:.2e})")
+        assert e_split < Z_ATOL and e_split < 1.5 * e_base + 1e-3
+        again = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_full=True)["full"].cpu()   # back on the default path, same workspace
+        assert torch.equal(again, base)
