@@ -20,7 +20,8 @@ What it restates (plain ``torch`` fp32/fp64 on the CPU, no HIP, no fused ops):
 
 Pinning status: the reference ships no tests, fixtures or golden vectors for this path
  and its own model code cannot be imported (LAVIS absent).  A4 is pinned
-against the HF port on shared seeded weights (``tests/test_oracle_vs_hf.py``, ``tests/golden``);
+against the HF port on shared seeded weights (live: ``tests/test_oracle.py``; committed vectors: ``tests/golden/qformer_*.npz``
+made by ``tools/make_golden.py``);
 A6 has no external pin at all: "parity unpinned" for the scorer, by construction.
 """
 from __future__ import annotations
