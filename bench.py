@@ -291,7 +291,7 @@ def main():
 def time_encode(dev, clips, frames_per_clip, fuse_s):
     """The encode stage (row A1 / N4), timed SEPARATELY from `value`: EVA ViT-g/14 over the clips x frames 224 x 224 frames
     that one step's video features stand for -- on this build's kernels (mra_vit_forward: one batched pass, GEMMs with fused
-    epilogues, attention core on heads zero-extended 88 -> 96 in LDS) and, beside it, as stock PyTorch f16 (SDPA + hipBLASLt).  Random weights; there is
+    epilogues, 96-padded attention core) and, beside it, as stock PyTorch f16 (SDPA + hipBLASLt).  Random weights; there is
     no BEATs source in this image, audio features stay synthetic."""
     from mraudio_amd.models.eva_vit import create_eva_vit_g
 

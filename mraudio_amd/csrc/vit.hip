@@ -12,11 +12,12 @@
 // the N = 1408 ones as full tiles plus a 128 x 512 tail tile per pair of row tiles, GemmProb::tile_cfg 8) with bias / GELU /
 // residual fused: the residual GEMMs START their accumulators at bias + residual, so their epilogue only stores.  The fp32
 // residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
-// Head dimension 88 is not a multiple of the MFMA K step: the attention core (vit_attn_kernel below) runs on 3 x 32-deep MFMA
-// steps over heads zero-extended to 96 -- the zero columns add nothing to any dot product.  Since round 3 the extension happens
-// on the core's LDS fill and Q | K | V leave the GEMM un-padded (N = 3 x 1408 = 4224 = 16 full column tiles + one 128-wide tail
-// tile per pair of row tiles on the mixed eight-phase kernel): the round-2 layout (QKV weight regrouped [q|k|v][head][96] with
-// eight zero rows per head) cost that GEMM 9 % of its flops and is kept only for geometries where 3 x dim is not 256 k + 128.
+// Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
+// per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
+// MFMA steps; the zero columns add nothing to any dot product.  (Round 3 measured the alternative -- Q | K | V un-padded out of the
+// GEMM, N = 4224 on the mixed eight-phase kernel, heads zero-extended on the core's LDS fill: the GEMM gains 72 us per 256 frames,
+// the core loses 54 on its 176-byte head rows, and over 1024 frames the encoder ran 575.5-576.7 against 571.7 ms in the same
+// session: not kept.  A run-time head stride in the core alone cost 30 % of it.)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,9 +50,7 @@ constexpr int ATT_WAVES = 9;
 // fragment 17 (all padding) is neither multiplied nor exponentiated; and the row sum comes out of the P V MFMAs themselves:
 // V's first padding column (d = hd) is set to one when the head is staged, so O^T[hd][query] = sum of the ROUNDED P row.
 template <typename T, int SC>
-__global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, T* ctx, int S_rt, int heads, int hd, int hs, float sl2) {
-  // hs: head stride inside a Q | K | V row: HD_PAD (the QKV GEMM wrote zero-padded heads) or hd (un-padded: the 16-byte pieces past hd are
-  // not read but filled with zeros here -- K -- or with the ones column -- V)
+__global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, T* ctx, int S_rt, int heads, int hd, float sl2) {
   const int S = SC ? SC : S_rt;
   const bool ones = hd < HD_PAD;    // a padding column exists: the row sum rides the MFMAs
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,9 +58,8 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
   char* Vs = smem + KS_PAD * KV_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frame = blockIdx.x / heads, head = blockIdx.x - frame * heads;
-  const int ld = 3 * heads * hs;
-  const T* base = qkv + (long long)frame * S * ld + head * hs;
-  const int nch = hs >> 3;          // 16-byte pieces per head that exist in memory
+  const int ld = 3 * heads * HD_PAD;
+  const T* base = qkv + (long long)frame * S * ld + head * HD_PAD;
   using V8 = typename Vec8<T>::type;
   // ---- K, V rows of this head -> LDS (rows past S zeroed).  Every load is issued before the first LDS write and none sits
   // under a lane-dependent branch (a clamped row is loaded and zeroed instead): one round trip, not one per chunk.
@@ -72,15 +70,15 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
     for (int u = 0; u < NCH; ++u) {
       const int c = min(tid + u * ATT_WAVES * 64, KS_PAD * 12 - 1);
       const int row = c / 12, ch = c - row * 12;
-      const T* p = base + (long long)min(row, S - 1) * ld + min(ch, nch - 1) * 8;   // a piece past the head: a valid address, zeroed below
-      kr[u] = *reinterpret_cast<const V8*>(p + heads * hs);
-      vr[u] = *reinterpret_cast<const V8*>(p + 2 * heads * hs);
+      const T* p = base + (long long)min(row, S - 1) * ld + ch * 8;
+      kr[u] = *reinterpret_cast<const V8*>(p + heads * HD_PAD);
+      vr[u] = *reinterpret_cast<const V8*>(p + 2 * heads * HD_PAD);
     }
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
       const int c = tid + u * ATT_WAVES * 64;
       const int row = c / 12, ch = c - row * 12;
-      if (row >= S || ch >= nch) {
+      if (row >= S) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kr[u][e] = from_f32<T>(0.f); vr[u][e] = kr[u][e]; }
       }
@@ -103,16 +101,9 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
     // Q fragments (B operand): lane (query lm, chunk lc) holds Q[q0 + lm][32 ks + 8 lc .. + 7]
     V8 qf[3];
     {
-      const T* qp = base + (long long)min(q0 + lm, S - 1) * ld;
+      const T* qp = base + (long long)min(q0 + lm, S - 1) * ld + 8 * lc;
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const int pc = 4 * ks + lc;                                   // 16-byte piece of the head
-        qf[ks] = *reinterpret_cast<const V8*>(qp + 8 * min(pc, nch - 1));
-        if (pc >= nch) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(0.f);
-        }
-      }
+      for (int ks = 0; ks < 3; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 32 * ks);
     }
     constexpr int NFR = SC ? (SC + 15) / 16 : KS_PAD / 16;   // key fragments with at least one valid key (compile-time S)
     f32x4 sc[KS_PAD / 16];
@@ -278,8 +269,6 @@ struct mra_vit {
   float *cls = nullptr, *pos = nullptr, *bpatch = nullptr;
   void* wpatch = nullptr;
   std::vector<VitLayer> layers;
-  bool qkv_padded = true;  // Q | K | V leave the GEMM zero-padded to 96 per head (false: un-padded on the eight-phase mixed kernel, N = 3 dim = 256 k + 128)
-  int hs = HD_PAD;         // head stride inside a Q | K | V row
   bool tail_tile = true;   // N = dim GEMMs: full 256-wide tiles + a 128 x 512 tail tile per pair of row tiles (false: a masked sixth 256-wide column tile)
   int proj_tile = 3;   // GemmProb::tile_cfg of the N = dim GEMMs: 256 x 256 with a masked last column tile (1408 = 5.5 tiles); the exact-fit
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
@@ -324,8 +313,7 @@ int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
   const mra_vit_cfg& c = *cfg;
   if (c.dim <= 0 || c.dim % 176 || c.dim % 64) return fail(MRA_EINVAL, "dim must be a multiple of 176 and of 64 (1408)");
   if (c.heads <= 0 || c.dim % c.heads || c.dim / c.heads > HD_PAD || (c.dim / c.heads) % 8) return fail(MRA_EINVAL, "head dimension must be a multiple of 8, <= 96");
-  if (c.mlp <= 0 || c.mlp % 256) return fail(MRA_EINVAL, "mlp must be a multiple of 256");
-  if (((3 * c.dim) % 256 != 128 || c.dim % 128) && (3 * c.heads * HD_PAD) % 256) return fail(MRA_EINVAL, "3 * dim must be 256 k + 128 (un-padded heads) or 3 * heads * 96 a multiple of 256");
+  if ((3 * c.heads * HD_PAD) % 256 || c.mlp <= 0 || c.mlp % 256) return fail(MRA_EINVAL, "3 * heads * 96 and mlp must be multiples of 256");
   if (c.patch <= 0 || c.img <= 0 || c.img % c.patch || c.depth <= 0) return fail(MRA_EINVAL, "bad patch / image size / depth");
   if (c.op_dtype != MRA_F16 && c.op_dtype != MRA_BF16) return fail(MRA_EINVAL, "op_dtype must be MRA_F16 or MRA_BF16");
   if (c.residual_dtype != MRA_F32 && c.residual_dtype != c.op_dtype) return fail(MRA_EINVAL, "residual_dtype must be MRA_F32 or the operand dtype");
@@ -335,12 +323,7 @@ int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
   h->S = h->np * h->np + 1;
   if (h->S > KS_PAD) { delete h; return fail(MRA_EINVAL, "more than 288 tokens per frame are not supported"); }
   h->kpad = (3 * c.patch * c.patch + 63) / 64 * 64;
-  // Round 3: the 88 -> 96 head padding cost the QKV GEMM 9 % of its flops.  Where 3 dim = 256 k + 128 (ViT-g: 4224) the GEMM runs un-padded on
-  // the eight-phase mixed kernel (full 256-wide tiles + one 128 x 512 tail tile per pair of row tiles) and the attention core zero-extends the
-  // heads on its LDS fill.
-  h->qkv_padded = !((3 * c.dim) % 256 == 128 && 3 * c.dim >= 384 && c.dim % 128 == 0);
-  h->hs = h->qkv_padded ? HD_PAD : c.dim / c.heads;
-  h->nqkv = 3 * c.heads * h->hs;
+  h->nqkv = 3 * c.heads * HD_PAD;
   HIP_TRY(hipGetDevice(&h->device));
   h->arena_bytes = vit_layout(h, nullptr);
   const hipError_t e = hipMalloc((void**)&h->arena, h->arena_bytes);
@@ -390,13 +373,13 @@ int mra_vit_load(mra_vit* h, const char* name, const void* src, int32_t dtype, c
     else if (sub == "norm1.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n1b, D, st); }
     else if (sub == "norm2.weight") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n2g, D, st); }
     else if (sub == "norm2.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.n2b, D, st); }
-    else if (sub == "attn.qkv.weight") { if ((rc = expect(3 * D * D))) return rc; rc = pack(L.wqkv, h->nqkv, (int)D, (int)D, h->qkv_padded ? 1 : 0); }
+    else if (sub == "attn.qkv.weight") { if ((rc = expect(3 * D * D))) return rc; rc = pack(L.wqkv, h->nqkv, (int)D, (int)D, 1); }
     else if (sub == "attn.q_bias" || sub == "attn.v_bias") {
       if ((rc = expect(D))) return rc;
       // [heads][hd] -> the q (or v) third of the padded bias [3][heads][96], as f32: one padded row-set of width 1
-      float* dst = L.bqkv + (sub == "attn.q_bias" ? 0 : 2) * c.heads * h->hs;
+      float* dst = L.bqkv + (sub == "attn.q_bias" ? 0 : 2) * c.heads * HD_PAD;
       for (int hh = 0; hh < c.heads && !rc; ++hh)
-        rc = launch_convert((const char*)src + (size_t)hh * hd * (dtype == MRA_F32 ? 4 : 2), dtype, dst + hh * h->hs, MRA_F32, hd, st);
+        rc = launch_convert((const char*)src + (size_t)hh * hd * (dtype == MRA_F32 ? 4 : 2), dtype, dst + hh * HD_PAD, MRA_F32, hd, st);
     }
     else if (sub == "attn.proj.weight") { if ((rc = expect(D * D))) return rc; rc = pack(L.wproj, D, (int)D, (int)D, 0); }
     else if (sub == "attn.proj.bias") { if ((rc = expect(D))) return rc; rc = copy_f32(src, dtype, L.bproj, D, st); }
@@ -489,16 +472,15 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       GemmProb p{};
       p.A = a16; p.a = plain((int)M, D); p.W = L.wqkv; p.bias = L.bqkv;
       p.C = big; p.c = plain((int)M, h->nqkv); p.M = (int)M; p.N = h->nqkv; p.K = D;
-      if (!h->qkv_padded) p.tile_cfg = 8;   // N = 4224 = 16 full column tiles + a 128-wide tail: the mixed eight-phase kernel
       rc = launch_gemm(&p, 1, EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
     if (S == 257) {   // ViT-g/224: the sequence length as a compile-time constant
-      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, h->hs, sl2);
-      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, h->hs, sl2);
+      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
     } else {
-      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, h->hs, sl2);
-      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, h->hs, sl2);
+      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
+      else hipLaunchKernelGGL((vit_attn_kernel<bf16, 0>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
     }
     // x += A W^T + b for the two N = dim GEMMs.  dim = 1408 is 5.5 tiles of 256: GemmProb::tile_cfg 8 runs the five full column tiles
     // of two row tiles and then their last 128 columns as one 128 x 512 tile, all in one launch (a masked sixth 256-wide tile wastes 9 %)

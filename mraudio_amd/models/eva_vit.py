@@ -135,8 +135,8 @@ class EvaViTg(nn.Module):
 class HipEvaViTg(EvaViTg):
     """The same encoder on the HIP extension (``mra_vit_*``, ``mraudio_amd/csrc/vit.hip``): this module is the parameter
     container (state_dict keys unchanged); ``forward`` runs ALL given frames as one batched pass of hand-written gfx950
-    kernels -- the four GEMMs per block on the eight-phase MFMA kernels with bias / GELU / residual fused, an
-    attention core on heads zero-extended 88 -> 96 in LDS -- and returns ``[n, 257, 1408]``: fp32 with the default fp32 residual stream, the operand dtype with
+    kernels -- the four GEMMs per block on the eight-phase MFMA kernels with bias / GELU / residual fused, a 96-padded
+    attention core -- and returns ``[n, 257, 1408]``: fp32 with the default fp32 residual stream, the operand dtype with
     ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  No CPU path."""
 
     def __init__(self, *args, op_dtype: torch.dtype = torch.float16, residual: str = "fp32", device=None, **kw):

@@ -1130,6 +1130,8 @@ int main(int argc, char** argv) {
   test_gemm(7, EPI_RES_F32, OP_F16, 1300, 384, 256, true);         // tile_cfg 8: 256-wide tiles + 128 x 512 tail tiles in one launch; odd number of row tiles
   test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);
+  test_gemm(7, EPI_OP, OP_F16, 1300, 384, 256, true);             // 16-bit outputs through the tail tile's LDS-staged epilogue (gemm_bench qkvpad: un-padded ViT QKV)
+  test_gemm(7, EPI_OP, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_F32, OP_F16, 700, 1408, 1408, false);
   // the ring kernel's exact-fit tiles (tile_cfg 9 / 10 / 11): every epilogue, ragged M, row views, two problems, 1 .. 48 K steps (fewer than,
   // exactly, and many more than the ring holds)

@@ -134,8 +134,7 @@ def test_other_frame_sizes_take_the_generic_attention_kernel(dev):
 def _launches():
     from mraudio_amd import _lib as L
 
-    # QKV: N = 3 x 1408 = 4224 = 16 full column tiles + a 128-wide tail -> the mixed eight-phase kernel, un-padded heads (round 3)
-    return {"qkv": L.gemm_launches(L.GF_P8_MIXED, L.EPI_OP), "fc1": L.gemm_launches(L.GF_P8_256, L.EPI_GELU_OP),
+    return {"qkv": L.gemm_launches(L.GF_P8_256, L.EPI_OP), "fc1": L.gemm_launches(L.GF_P8_256, L.EPI_GELU_OP),
             "res32": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_F32), "res16": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_OP)}
 
 
@@ -156,9 +155,9 @@ def depth2(dev):
 
 @pytest.mark.parametrize("residual", ["fp32", "op"])
 def test_eight_phase_gemms_of_the_shipped_library_at_32_frames(depth2, dev, residual):
-    """32 frames = 8224 rows = 33 row tiles: fc1 + GELU (792 tiles) runs on ``gemm_p8_kernel<EPI_GELU_OP>`` of the SHIPPED library
-    (launch counters), QKV (un-padded, N = 4224), projection and fc2 on ``gemm_p8_mixed_kernel`` (full 256-wide tiles + 128 x 512 tail
-    tiles); an odd number of row tiles, a ragged last one.  Against the fp32 CPU restatement at the bars of the small-batch tests."""
+    """32 frames = 8224 rows = 33 row tiles: QKV (594 tiles) and fc1 + GELU (792 tiles) run on ``gemm_p8_kernel<EPI_OP>`` /
+    ``<EPI_GELU_OP>`` of the SHIPPED library (launch counters), projection / fc2 on ``gemm_p8_mixed_kernel``; an odd number of row
+    tiles, a ragged last one.  Against the fp32 CPU restatement at the bars of the small-batch tests."""
     ref, hips, frames, want = depth2
     before = _launches()
     y = hips[residual](frames.to(dev)).float().cpu()
