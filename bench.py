@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--cross-precision", default="op", choices=["op", "split"],
                     help="precision of the cross-attention score chain: op = f16 / bf16 operands (default); split = hi + lo pairs (~22 bits) for sharply attending weights")
     ap.add_argument("--chain-ring", type=int, default=-1, help="A/B: mask of chain GEMMs on the ring kernel's tiles (1 QKV, 2 FFN-up, 4 residual projections; -1 = library default)")
+    ap.add_argument("--pair", action="store_true", help="A/B: the two modality Q-Formers as ONE grouped launch sequence (mra_qformer_forward_pair) instead of two forwards on two streams; "
+                                                        "measured slower (6.72-6.87 vs 6.57 ms per step), although the folded block runs at 0.65 instead of 0.79 ms")
     ap.add_argument("--no-priority", action="store_true", help="A/B: same stream priority for both modalities")
     ap.add_argument("--no-kv-first", action="store_true", help="A/B: let the light modality start beside the heavy K/V projection")
     ap.add_argument("--no-encode", action="store_true", help="skip the separately timed ViT-g encode stage")
@@ -113,6 +115,7 @@ def main():
     op_dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
     # BERT-style synthetic weights, seed 0: N(0, 0.02) matrices, zero biases, unit LayerNorms
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=op_dtype, device=dev)
+    model.pair_forward = args.pair
     model.kv_first = not args.no_kv_first
     model.prioritize_heavy = not args.no_priority
     for m in ("video", "audio"):
@@ -248,6 +251,7 @@ def main():
                 "encoders": "not part of value (synthetic features stand in for ViT-g / BEATs outputs); the ViT-g encode of the same frames is timed separately under encode_stage",
                 "weights": "synthetic BERT init, seed 0",
                 "cross_attention": "folded" if folded else "kv_cache", "cross_precision": args.cross_precision,
+                "modalities": "one grouped launch sequence (mra_qformer_forward_pair)" if (args.pair and args.cross_precision == "op" and args.cross_mode != "fold_stream") else "two forwards on two streams",
             },
             "executed_tflops_per_gpu": round(flops_exec * args.steps / dt / 1e12, 1),
             "algorithmic_tflops_per_gpu": round(flops_step * args.steps / dt / 1e12, 1),

@@ -125,6 +125,21 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
 size_t mra_kv_cache_bytes(mra_qformer* h, int32_t items, int32_t kv);
 int mra_kv_project(mra_qformer* h, const void* enc, int32_t items, int32_t kv, void* kv_cache, void* stream);
 
+/* Two Q-Formers of equal shape (hidden / heads / inter / layers / cross_freq / n_query / operand dtype) over the SAME prompt in one launch
+ * sequence: replaces the two `{m}_Qformer.bert(...)` calls of one step (models/xinstructblip.py:286-293, once per modality).  The layer
+ * chains -- identical in shape for every modality -- run as grouped launches (each chain GEMM takes both lanes' problems, the self-attention
+ * cores and LayerNorms take the 2 x items rows as one launch); each lane keeps its own cross-attention (encoder width, Kv and formulation may
+ * differ).  A chain launch at ~2 k rows is half fixed cost: the grouped sequence spends 0.7 ms less kernel time per
+ * headline step and its folded blocks run undisturbed (0.65 instead of 0.79 ms) -- but two forwards on two streams hide ~0.65 ms of the light
+ * modality behind the heavy one's latency-bound phases, which one sequence cannot: measured 6.72-6.87 vs 6.57 ms per step.  Kept as a
+ * tested alternative (Python: model.pair_forward = True).  Same arithmetic per lane as mra_qformer_forward
+ * (learned query tokens, operand-dtype score chain); outputs: out_query [items, 32, H] and / or out_cls [items, H] per lane (fp32).
+ * Workspace: mra_qformer_pair_workspace_bytes. */
+size_t mra_qformer_pair_workspace_bytes(mra_qformer* h0, mra_qformer* h1, int32_t items, int32_t L, int32_t kv0, int32_t kv1);
+int mra_qformer_forward_pair(mra_qformer* h0, mra_qformer* h1, const int64_t* input_ids, const int64_t* attention_mask, const void* enc0,
+                             const void* enc1, int32_t items, int32_t L, int32_t kv0, int32_t kv1, float* out_query0, float* out_cls0,
+                             float* out_query1, float* out_cls1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Optional instrumentation for bench.py: when both events (hipEvent_t passed as void*) are non-NULL,
  * every following mra_qformer_forward records ev_start right before and ev_stop right after its
  * K/V-projection launch, on the launch stream.  (NULL, NULL) switches it off. */

@@ -49,6 +49,9 @@ PROTOTYPES = {
     "mra_qformer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),
+    "mra_qformer_pair_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mra_qformer_forward_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mra_qformer_set_kv_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mra_qformer_set_kv_done_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mra_qformer_set_cross_mode": (C.c_int, [C.c_void_p, C.c_int32]),

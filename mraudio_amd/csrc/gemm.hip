@@ -60,7 +60,10 @@ __device__ __forceinline__ GemmProb pick_tile(const GemmArgs& args, int& n0, int
 // tile `id` of the launch (after the XCD remap): its problem (batch entry applied) and origin
 template <int TN, int TM>
 __device__ __forceinline__ GemmProb tile_of(const GemmArgs& args, int id, int& n0, int& m0) {
-  const int g = (args.ngroups > 1 && id >= args.p[1].tile_begin) ? 1 : 0;
+  int g = 0;   // the last problem whose first tile is <= id (tile_begin ascends)
+#pragma unroll
+  for (int k = 1; k < GEMM_MAX_GROUPS; ++k)
+    if (k < args.ngroups && id >= args.p[k].tile_begin) g = k;
   GemmProb P = args.p[g];
   int pid = id - P.tile_begin;
   if (P.batch > 1) {   // batch entry first, then the panel order inside it
@@ -1653,7 +1656,7 @@ int gemm_pick_config(const GemmProb* probs, int ngroups) {
 }
 
 int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipStream_t stream) {
-  if (ngroups < 1 || ngroups > 2) return -1;
+  if (ngroups < 1 || ngroups > GEMM_MAX_GROUPS) return -1;
   const int cfg = gemm_pick_config(probs, ngroups);
   if (cfg < 0 || cfg > 10) return -1;
   const int t = kTileN[cfg], tm = kTileM[cfg];
@@ -1694,7 +1697,7 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (cfg == 7) tiles += (p.mtiles + 1) / 2 * (2 * (p.N >> 8) + 1);   // per pair of row tiles: 2 k full tiles + one tail tile
     else tiles += p.mtiles * p.ntiles * (p.batch > 1 ? p.batch : 1);
   }
-  if (ngroups == 1) a.p[1] = a.p[0];
+  for (int g = ngroups; g < GEMM_MAX_GROUPS; ++g) a.p[g] = a.p[0];
   a.total_tiles = tiles;
   a.dbg = g_dbg;
   a.order = g_order ? g_order : probs[0].order;

@@ -104,8 +104,9 @@ struct GemmProb {
   int batch_row0;  // filled per workgroup: first row of its batch entry in the EPI_SOFTPART statistics
 };
 
+constexpr int GEMM_MAX_GROUPS = 4;   // problems per launch (round 3: the pair forward groups the query / text problems of two Q-Formers)
 struct GemmArgs {
-  GemmProb p[2];
+  GemmProb p[GEMM_MAX_GROUPS];
   int ngroups;
   int total_tiles;
   unsigned long long* dbg;  // diagnostic builds only (gemm_set_debug_buffer): per-wave cycle sums
@@ -285,6 +286,11 @@ int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gai
 int launch_ln_rows2(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2,
                     const float* bias2, int period, int split, float eps, float* y32, RowView y32v, void* y16, RowView y16v,
                     int op_dtype, hipStream_t stream);
+// two Q-Formers in one launch (pair forward): rows [0, lane_rows) as launch_ln_rows2 with sets (1, 2), rows from lane_rows on with sets (3, 4)
+// (gain4 == nullptr: set 3 for all of them)
+int launch_ln_rows4(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2, const float* bias2,
+                    int lane_rows, const float* gain3, const float* bias3, const float* gain4, const float* bias4, int period, int split,
+                    float eps, float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream);
 // Modality LayerNorm (A2) fused with the item gather (A3): out item i <- LN(in item index[i]).
 // x dtype: 0 = f32, 1 = f16, 2 = bf16.
 int launch_modality_ln(const void* x, int x_dtype, const long long* item_index, int items, int tokens, int E,

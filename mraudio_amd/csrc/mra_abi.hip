@@ -161,24 +161,27 @@ struct Work {
   size_t bytes;
 };
 
-Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
-  const mra_cfg& c = h->cfg;
-  const size_t H = c.hidden, I = c.inter, S = c.n_query + L, Q = c.n_query;
-  Carver cv(base);
-  Work w;
-  w.hA32 = cv.take<float>(N * S * H);
-  w.hB32 = cv.take<float>(N * S * H);
-  w.pre32 = cv.take<float>(N * S * H);
-  w.hC32 = cv.take<float>(N * Q * H);
-  w.hA16 = cv.take<char>(N * S * H, 2);
-  w.hB16 = cv.take<char>(N * S * H, 2);
-  w.qkv16 = cv.take<char>(N * S * 3 * H, 2);
-  w.ctx16 = cv.take<char>(N * S * H, 2);
-  w.qc16 = cv.take<char>(N * Q * H, 2);
-  w.hC16 = cv.take<char>(N * Q * H, 2);
-  w.ffn16 = cv.take<char>(N * S * I, 2);
-  w.lncnt_bytes = 2 * ((size_t)N * S / 64 + 2) * sizeof(unsigned);
+// the layer chain's buffers for NN items (residual streams, QKV, attention context, feed-forward intermediate)
+void layout_chain(Carver& cv, Work& w, size_t NN, size_t S, size_t H, size_t I, size_t Q) {
+  w.hA32 = cv.take<float>(NN * S * H);
+  w.hB32 = cv.take<float>(NN * S * H);
+  w.pre32 = cv.take<float>(NN * S * H);
+  w.hC32 = cv.take<float>(NN * Q * H);
+  w.hA16 = cv.take<char>(NN * S * H, 2);
+  w.hB16 = cv.take<char>(NN * S * H, 2);
+  w.qkv16 = cv.take<char>(NN * S * 3 * H, 2);
+  w.ctx16 = cv.take<char>(NN * S * H, 2);
+  w.qc16 = cv.take<char>(NN * Q * H, 2);
+  w.hC16 = cv.take<char>(NN * Q * H, 2);
+  w.ffn16 = cv.take<char>(NN * S * I, 2);
+  w.lncnt_bytes = 2 * (NN * S / 64 + 2) * sizeof(unsigned);
   w.lncnt = cv.take<unsigned>(w.lncnt_bytes / sizeof(unsigned));
+}
+
+// one handle's cross-attention buffers for N items (K/V cache, or the folded form's Q' / P / U / statistics)
+void layout_cross(const mra_qformer* h, Carver& cv, Work& w, int N, int Kv) {
+  const mra_cfg& c = h->cfg;
+  const size_t H = c.hidden, Q = c.n_query;
   w.kv16 = w.encT = w.qp16 = w.p16 = w.u16 = w.hs16 = w.qs16 = nullptr;
   w.qc32 = w.qp32 = nullptr;
   w.s32 = w.stat = w.gfac = w.st_m = w.st_l = w.ginv = nullptr;
@@ -213,10 +216,185 @@ Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
     w.kv16 = cv.take<char>((size_t)h->ncross * 2 * N * Kv * H, 2);
   }
   w.nsplit = attn_pick_split(N, c.heads, (int)Q, Kv);
-  w.part = nullptr;  // grid-split attention partials live right behind `bytes` (set by the caller)
+  w.part = nullptr;
+}
+
+Work layout_work(const mra_qformer* h, char* base, int N, int L, int Kv) {
+  const mra_cfg& c = h->cfg;
+  Carver cv(base);
+  Work w;
+  layout_chain(cv, w, (size_t)N, (size_t)c.n_query + L, c.hidden, c.inter, c.n_query);
+  layout_cross(h, cv, w, N, Kv);   // w.part: grid-split attention partials live right behind `bytes` (set by the caller)
   w.bytes = cv.off;
   return w;
 }
+
+// Pair forward: the layer chains of two Q-Formers of equal shape in ONE launch sequence.  The chain buffers hold 2 N items (lane 0's, then
+// lane 1's), so attention cores and LayerNorms take both lanes as one launch and every chain GEMM groups the lanes' problems; each lane
+// keeps its own cross-attention buffers.
+struct PairWork {
+  Work w[2];
+  long long* mask2;   // attention mask rows of both lanes [2 N][S]
+  size_t bytes;
+};
+
+PairWork layout_pair(const mra_qformer* h0, const mra_qformer* h1, char* base, int N, int L, int kv0, int kv1) {
+  const mra_cfg& c = h0->cfg;
+  const size_t H = c.hidden, I = c.inter, Q = c.n_query, S = Q + L;
+  Carver cv(base);
+  PairWork pw;
+  Work sh;
+  layout_chain(cv, sh, (size_t)2 * N, S, H, I, Q);
+  const mra_qformer* hs[2] = {h0, h1};
+  const int kvs[2] = {kv0, kv1};
+  for (int l = 0; l < 2; ++l) {
+    Work& w = pw.w[l];
+    w = sh;
+    const size_t n = (size_t)l * N;
+    w.hA32 = sh.hA32 ? sh.hA32 + n * S * H : nullptr; w.hB32 = sh.hB32 ? sh.hB32 + n * S * H : nullptr; w.pre32 = sh.pre32 ? sh.pre32 + n * S * H : nullptr;
+    w.hC32 = sh.hC32 ? sh.hC32 + n * Q * H : nullptr;
+    w.hA16 = sh.hA16 ? sh.hA16 + n * S * H * 2 : nullptr; w.hB16 = sh.hB16 ? sh.hB16 + n * S * H * 2 : nullptr;
+    w.qkv16 = sh.qkv16 ? sh.qkv16 + n * S * 3 * H * 2 : nullptr; w.ctx16 = sh.ctx16 ? sh.ctx16 + n * S * H * 2 : nullptr;
+    w.qc16 = sh.qc16 ? sh.qc16 + n * Q * H * 2 : nullptr; w.hC16 = sh.hC16 ? sh.hC16 + n * Q * H * 2 : nullptr;
+    w.ffn16 = sh.ffn16 ? sh.ffn16 + n * S * I * 2 : nullptr;
+    layout_cross(hs[l], cv, w, N, kvs[l]);
+    float* part = cv.take<float>(attn_partial_bytes(N, c.heads, (int)Q, w.nsplit) / sizeof(float) + 64);
+    w.part = w.nsplit > 1 ? part : nullptr;
+    w.bytes = 0;
+  }
+  pw.mask2 = cv.take<long long>((size_t)2 * N * S);
+  pw.bytes = cv.off;
+  return pw;
+}
+
+// Steps 6 / 6a-6e of one cross-attention layer: from the query projection Q (w.qc16, or w.qc32 in split precision) to the attention
+// context (w.ctx16 [N*Q][H]) -- the folded form (per-head Q' GEMM, scores + split softmax, P . enc, per-head context GEMM) or the core over the
+// head-major K/V cache.  Shared by mra_qformer_forward and mra_qformer_forward_pair.
+int cross_core(mra_qformer* h, const Work& w, const LayerW& Lw, const void* enc, int N, int kv, bool fold, bool stream_fold, bool precise,
+               hipStream_t stream) {
+  const mra_cfg& c = h->cfg;
+  const int Q = c.n_query, H = c.hidden, E = c.enc_width, R = c.heads * Q, kvp = fold_kvp(kv), op = h->op();
+  const size_t esz = 2;
+  const RowView qc_rows = plain(N * Q, H);
+  int rc = 0;
+  if (fold) {
+    const int ci = Lw.cross_index;
+    const bool timed = ci == 0 && h->kv_ev0 && h->kv_ev1;
+    if (timed) (void)hipEventRecord(h->kv_ev0, stream);
+    // 6a. Q' = Q_h W_k,h per head: [N*32, 64] x [E, 64]^T -> Q' [N][head*32 + q][E]
+    GemmProb d{};
+    if (precise) {
+      // Q (fp32) per head as (hi | lo | hi) over its 64 dims against W_k,h as (hi | hi | lo): K = 192; Q' in fp32, then as (hi | lo) rows
+      rc = launch_split_rows(w.qc32, qc_rows, N * Q, H, 64, 3, w.qs16, op, stream);
+      if (rc) return chk(rc, "split cross query");
+      d.A = w.qs16; d.a = plain(N * Q, 3 * H); d.a_bs = 192;
+      d.W = h->arena_p + (size_t)ci * precise_layer_bytes(h) + precise_wk_off(h); d.w_bs = (long long)E * 192;
+      d.C = w.qp32; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * 4;
+      d.M = N * Q; d.N = E; d.K = 192; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
+      rc = launch_gemm(&d, 1, EPI_F32, op, stream);
+      if (rc) return chk(rc, "fold q' gemm (split precision)");
+      rc = launch_split_rows(w.qp32, plain(N * R, E), N * R, E, E, 2, w.qp16, op, stream);
+      if (rc) return chk(rc, "split q'");
+    } else {
+    d.A = w.qc16; d.a = qc_rows; d.a_bs = 64;
+    d.W = h->arena_f + (size_t)ci * H * E * esz; d.w_bs = (long long)E * 64;
+    d.C = w.qp16; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * esz;
+    d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
+    rc = launch_gemm(&d, 1, EPI_OP, op, stream);
+    if (rc) return chk(rc, "fold q' gemm");
+    }
+    if (stream_fold) {
+      // 6b-6d on the streaming kernels (fold_stream.hip): P~ = exp2(s - ceil(tile max)) + tile statistics, row statistics,
+      // U = (1 / L) sum g P~ enc with the power-of-two tile factors applied in registers.  P~ is written once, read once.
+      FoldStreamArgs fs{};
+      fs.qp = w.qp16; fs.qpb = w.encT; fs.enc = enc; fs.p = w.p16; fs.u = w.u16;
+      fs.stat_m = w.st_m; fs.stat_l = w.st_l; fs.gexp = w.gexp; fs.ginv = w.ginv;
+      fs.items = N; fs.kv = kv; fs.kvp = kvp; fs.E = E;
+      fs.alpha = 0.125f * 1.4426950408889634f; fs.phase = 3;
+      rc = launch_fold_stream(fs, stream);
+      if (rc) return chk(rc, "fold scores / P.enc (streaming kernels)");
+    } else {
+    // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, rows padded to kvp columns
+    GemmProb sc{};
+    sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
+    sc.W = enc; sc.w_bs = (long long)kv * E;
+    sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1;
+    if (precise) {   // Q' rows are (hi | lo): two passes over the same encoder slab inside one K loop
+      sc.a = plain(R, 2 * E); sc.a_bs = (long long)R * 2 * E; sc.K = 2 * E; sc.w_kwrap = E / 64;
+    }
+    sc.tile_cfg = (R == 384 && h->sc_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
+    if (sc.tile_cfg == 5 && h->split_softmax) {
+      // 6b + 6c fused: the GEMM's epilogue leaves exp2(s - tile maximum) in the operand dtype plus tile statistics;
+      // one pass over P rescales every row by exp2(m_tile - m_row) / sum.  The scores never exist in fp32 in HBM.
+      const int ntiles = (kv + 175) / 176;
+      sc.C = w.p16; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * esz;
+      sc.alpha = 0.125f * 1.4426950408889634f;
+      sc.stat_m = w.stat; sc.stat_l = w.stat + (size_t)N * R * ntiles;
+      rc = launch_gemm(&sc, 1, EPI_SOFTPART, op, stream);
+      if (rc) return chk(rc, "fold scores gemm (softmax partials)");
+      if (w.gfac) {
+        // second half of the softmax without a pass over P: only the row factors are computed here, the P . enc GEMM applies them
+        // to its P~ fragments in registers (same arithmetic, same rounding as the rescale pass)
+        rc = launch_fold_rowfactor(sc.stat_m, sc.stat_l, w.gfac, N * R, R, ntiles, w.p16, kvp, 176, kvp, stream);
+        if (rc) return chk(rc, "fold row factors");
+      } else {
+        rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);
+        if (rc) return chk(rc, "fold softmax rescale");
+      }
+    } else {
+      sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;   // fp32 rows
+      rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
+      if (rc) return chk(rc, "fold scores gemm");
+      // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
+      rc = launch_softmax_rows(w.s32, kvp, w.p16, kvp, N * R, kv, kvp, 0.125f, op, stream);
+      if (rc) return chk(rc, "fold softmax");
+    }
+    // 6d. U[n] = P[n] enc[n]: [R, kvp] x [E, kvp]^T per item
+    GemmProb pv{};
+    pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
+    if (fold_kmajor(h)) {   // the encoder tokens themselves: [kv][E] is W K-major; rows kv .. kvp repeat the last token against P = 0
+      pv.W = enc; pv.w_bs = (long long)kv * E; pv.w_ld = E; pv.k_rows = kv;
+    } else {
+      pv.W = w.encT; pv.w_bs = (long long)E * kvp;
+    }
+    pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
+    pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N;
+    pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
+    if (w.gfac && sc.tile_cfg == 5 && h->split_softmax) { pv.pscale = w.gfac; pv.ps_ntiles = (kv + 175) / 176; }
+    rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
+    if (rc) return chk(rc, "fold p.enc gemm");
+    }
+    // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]
+    GemmProb cx{};
+    cx.A = w.u16; cx.a = items_view((long long)R * E, Q, E); cx.a_bs = (long long)Q * E;
+    cx.W = (const char*)h->wkv + (size_t)(ci * 2 + 1) * H * E * esz; cx.w_bs = (long long)64 * E;
+    cx.bias = h->bkv + (size_t)(ci * 2 + 1) * H; cx.bias_bs = 64;
+    cx.C = w.ctx16; cx.c = qc_rows; cx.c_bs_bytes = 64 * esz;
+    cx.M = N * Q; cx.N = 64; cx.K = E; cx.batch = c.heads; cx.tile_cfg = E % 128 == 0 && N * Q >= 512 ? 6 : 1;
+    rc = launch_gemm(&cx, 1, EPI_OP, op, stream);
+    if (rc) return chk(rc, "fold context gemm");
+    if (timed) (void)hipEventRecord(h->kv_ev1, stream);
+  } else {
+  // 6. cross-attention core over the head-major K/V cache
+  AttnArgs a{};
+  const size_t per_sel = (size_t)N * c.heads * kv * 64;
+  a.Q = w.qc16;
+  a.K = w.kv16 + (size_t)(Lw.cross_index * 2 + 0) * per_sel * esz;
+  a.V = w.kv16 + (size_t)(Lw.cross_index * 2 + 1) * per_sel * esz;
+  a.O = w.ctx16;
+  a.q_item_stride = (long long)Q * H; a.q_ld = H;
+  a.k_item_stride = (long long)c.heads * kv * 64; a.k_head_stride = (long long)kv * 64; a.k_ld = 64;
+  a.v_item_stride = a.k_item_stride; a.v_head_stride = a.k_head_stride; a.v_ld = 64;
+  a.o_item_stride = (long long)Q * H; a.o_ld = H;
+  a.mask = nullptr; a.mask_ld = 0;
+  a.items = N; a.heads = c.heads; a.q_rows = Q; a.kv_len = kv;
+  a.scale = 0.125f; a.nsplit = w.nsplit; a.part = w.part;
+  rc = launch_attention(a, op, stream);
+  if (rc) return chk(rc, "cross attention");
+  }
+  return MRA_OK;
+}
+
 
 }  // namespace
 
@@ -575,121 +753,7 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
         rc = launch_gemm(&p, 1, EPI_OP, op, stream);
       }
       if (rc) return chk(rc, "cross q gemm");
-      if (fold) {
-        const int ci = Lw.cross_index;
-        const bool timed = ci == 0 && h->kv_ev0 && h->kv_ev1;
-        if (timed) (void)hipEventRecord(h->kv_ev0, stream);
-        // 6a. Q' = Q_h W_k,h per head: [N*32, 64] x [E, 64]^T -> Q' [N][head*32 + q][E]
-        GemmProb d{};
-        if (precise) {
-          // Q (fp32) per head as (hi | lo | hi) over its 64 dims against W_k,h as (hi | hi | lo): K = 192; Q' in fp32, then as (hi | lo) rows
-          rc = launch_split_rows(w.qc32, qc_rows, N * Q, H, 64, 3, w.qs16, op, stream);
-          if (rc) return chk(rc, "split cross query");
-          d.A = w.qs16; d.a = plain(N * Q, 3 * H); d.a_bs = 192;
-          d.W = h->arena_p + (size_t)ci * precise_layer_bytes(h) + precise_wk_off(h); d.w_bs = (long long)E * 192;
-          d.C = w.qp32; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * 4;
-          d.M = N * Q; d.N = E; d.K = 192; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
-          rc = launch_gemm(&d, 1, EPI_F32, op, stream);
-          if (rc) return chk(rc, "fold q' gemm (split precision)");
-          rc = launch_split_rows(w.qp32, plain(N * R, E), N * R, E, E, 2, w.qp16, op, stream);
-          if (rc) return chk(rc, "split q'");
-        } else {
-        d.A = w.qc16; d.a = qc_rows; d.a_bs = 64;
-        d.W = h->arena_f + (size_t)ci * H * E * esz; d.w_bs = (long long)E * 64;
-        d.C = w.qp16; d.c = items_view((long long)R * E, Q, E); d.c_bs_bytes = (long long)Q * E * esz;
-        d.M = N * Q; d.N = E; d.K = 64; d.batch = c.heads; d.tile_cfg = (N * Q) % 128 == 0 && E % 128 == 0 ? 2 : 1;
-        rc = launch_gemm(&d, 1, EPI_OP, op, stream);
-        if (rc) return chk(rc, "fold q' gemm");
-        }
-        if (stream_fold) {
-          // 6b-6d on the streaming kernels (fold_stream.hip): P~ = exp2(s - ceil(tile max)) + tile statistics, row statistics,
-          // U = (1 / L) sum g P~ enc with the power-of-two tile factors applied in registers.  P~ is written once, read once.
-          FoldStreamArgs fs{};
-          fs.qp = w.qp16; fs.qpb = w.encT; fs.enc = enc; fs.p = w.p16; fs.u = w.u16;
-          fs.stat_m = w.st_m; fs.stat_l = w.st_l; fs.gexp = w.gexp; fs.ginv = w.ginv;
-          fs.items = N; fs.kv = kv; fs.kvp = kvp; fs.E = E;
-          fs.alpha = 0.125f * 1.4426950408889634f; fs.phase = 3;
-          rc = launch_fold_stream(fs, stream);
-          if (rc) return chk(rc, "fold scores / P.enc (streaming kernels)");
-        } else {
-        // 6b. scores S[n] = Q'[n] enc[n]^T: [R, E] x [kv, E]^T per item, rows padded to kvp columns
-        GemmProb sc{};
-        sc.A = w.qp16; sc.a = plain(R, E); sc.a_bs = (long long)R * E;
-        sc.W = enc; sc.w_bs = (long long)kv * E;
-        sc.M = R; sc.N = kv; sc.K = E; sc.batch = N; sc.n_ragged = 1;
-        if (precise) {   // Q' rows are (hi | lo): two passes over the same encoder slab inside one K loop
-          sc.a = plain(R, 2 * E); sc.a_bs = (long long)R * 2 * E; sc.K = 2 * E; sc.w_kwrap = E / 64;
-        }
-        sc.tile_cfg = (R == 384 && h->sc_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
-        if (sc.tile_cfg == 5 && h->split_softmax) {
-          // 6b + 6c fused: the GEMM's epilogue leaves exp2(s - tile maximum) in the operand dtype plus tile statistics;
-          // one pass over P rescales every row by exp2(m_tile - m_row) / sum.  The scores never exist in fp32 in HBM.
-          const int ntiles = (kv + 175) / 176;
-          sc.C = w.p16; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * esz;
-          sc.alpha = 0.125f * 1.4426950408889634f;
-          sc.stat_m = w.stat; sc.stat_l = w.stat + (size_t)N * R * ntiles;
-          rc = launch_gemm(&sc, 1, EPI_SOFTPART, op, stream);
-          if (rc) return chk(rc, "fold scores gemm (softmax partials)");
-          if (w.gfac) {
-            // second half of the softmax without a pass over P: only the row factors are computed here, the P . enc GEMM applies them
-            // to its P~ fragments in registers (same arithmetic, same rounding as the rescale pass)
-            rc = launch_fold_rowfactor(sc.stat_m, sc.stat_l, w.gfac, N * R, R, ntiles, w.p16, kvp, 176, kvp, stream);
-            if (rc) return chk(rc, "fold row factors");
-          } else {
-            rc = launch_softmax_rescale(w.p16, kvp, sc.stat_m, sc.stat_l, N * R, ntiles, 176, kvp, op, stream);
-            if (rc) return chk(rc, "fold softmax rescale");
-          }
-        } else {
-          sc.C = w.s32; sc.c = plain(R, kvp); sc.c_bs_bytes = (long long)R * kvp * 4;   // fp32 rows
-          rc = launch_gemm(&sc, 1, EPI_F32, op, stream);
-          if (rc) return chk(rc, "fold scores gemm");
-          // 6c. P = softmax(S / 8) row by row (the key bias is constant along a row and cancels)
-          rc = launch_softmax_rows(w.s32, kvp, w.p16, kvp, N * R, kv, kvp, 0.125f, op, stream);
-          if (rc) return chk(rc, "fold softmax");
-        }
-        // 6d. U[n] = P[n] enc[n]: [R, kvp] x [E, kvp]^T per item
-        GemmProb pv{};
-        pv.A = w.p16; pv.a = plain(R, kvp); pv.a_bs = (long long)R * kvp;
-        if (fold_kmajor(h)) {   // the encoder tokens themselves: [kv][E] is W K-major; rows kv .. kvp repeat the last token against P = 0
-          pv.W = enc; pv.w_bs = (long long)kv * E; pv.w_ld = E; pv.k_rows = kv;
-        } else {
-          pv.W = w.encT; pv.w_bs = (long long)E * kvp;
-        }
-        pv.C = w.u16; pv.c = plain(R, E); pv.c_bs_bytes = (long long)R * E * esz;
-        pv.M = R; pv.N = E; pv.K = kvp; pv.batch = N;
-        pv.tile_cfg = (R == 384 && E % 176 == 0 && h->pv_tile == 5) ? 5 : (R == 384 ? h->fold_tile : 2);
-        if (w.gfac && sc.tile_cfg == 5 && h->split_softmax) { pv.pscale = w.gfac; pv.ps_ntiles = (kv + 175) / 176; }
-        rc = launch_gemm(&pv, 1, EPI_OP, op, stream);
-        if (rc) return chk(rc, "fold p.enc gemm");
-        }
-        // 6e. context = U_h W_v,h^T + b_v,h per head: [N*32, E] x [64, E]^T -> ctx [N*32][head*64 + d]
-        GemmProb cx{};
-        cx.A = w.u16; cx.a = items_view((long long)R * E, Q, E); cx.a_bs = (long long)Q * E;
-        cx.W = (const char*)h->wkv + (size_t)(ci * 2 + 1) * H * E * esz; cx.w_bs = (long long)64 * E;
-        cx.bias = h->bkv + (size_t)(ci * 2 + 1) * H; cx.bias_bs = 64;
-        cx.C = w.ctx16; cx.c = qc_rows; cx.c_bs_bytes = 64 * esz;
-        cx.M = N * Q; cx.N = 64; cx.K = E; cx.batch = c.heads; cx.tile_cfg = E % 128 == 0 && N * Q >= 512 ? 6 : 1;
-        rc = launch_gemm(&cx, 1, EPI_OP, op, stream);
-        if (rc) return chk(rc, "fold context gemm");
-        if (timed) (void)hipEventRecord(h->kv_ev1, stream);
-      } else {
-      // 6. cross-attention core over the head-major K/V cache
-      AttnArgs a{};
-      const size_t per_sel = (size_t)N * c.heads * kv * 64;
-      a.Q = w.qc16;
-      a.K = w.kv16 + (size_t)(Lw.cross_index * 2 + 0) * per_sel * esz;
-      a.V = w.kv16 + (size_t)(Lw.cross_index * 2 + 1) * per_sel * esz;
-      a.O = w.ctx16;
-      a.q_item_stride = (long long)Q * H; a.q_ld = H;
-      a.k_item_stride = (long long)c.heads * kv * 64; a.k_head_stride = (long long)kv * 64; a.k_ld = 64;
-      a.v_item_stride = a.k_item_stride; a.v_head_stride = a.k_head_stride; a.v_ld = 64;
-      a.o_item_stride = (long long)Q * H; a.o_ld = H;
-      a.mask = nullptr; a.mask_ld = 0;
-      a.items = N; a.heads = c.heads; a.q_rows = Q; a.kv_len = kv;
-      a.scale = 0.125f; a.nsplit = w.nsplit; a.part = w.part;
-      rc = launch_attention(a, op, stream);
-      if (rc) return chk(rc, "cross attention");
-      }
+      if ((rc = cross_core(h, w, Lw, enc, N, kv, fold, stream_fold, precise, stream))) return rc;
       // 7. output projection + residual (hB[:, :32]), 8. LayerNorm -> hC (compact)
       GemmProb o{};
       o.A = w.ctx16; o.a = qc_rows;
@@ -810,6 +874,215 @@ int mra_qformer_forward(mra_qformer* h, const int64_t* input_ids, const int64_t*
           rc = launch_ln_rows(w.pre32 + t_off32, cls_view, N, H, Lw.lntg, Lw.lntb, c.ln_eps, out_cls, plain(N, H), nullptr,
                               plain(N, H), op, stream);
           if (rc) return chk(rc, "final cls ln");
+        }
+      }
+    }
+  }
+  return MRA_OK;
+}
+
+size_t mra_qformer_pair_workspace_bytes(mra_qformer* h0, mra_qformer* h1, int32_t items, int32_t L, int32_t kv0, int32_t kv1) {
+  if (!h0 || !h1 || items <= 0 || L < 0 || kv0 <= 0 || kv1 <= 0) return 0;
+  return layout_pair(h0, h1, nullptr, items, L, kv0, kv1).bytes;
+}
+
+int mra_qformer_forward_pair(mra_qformer* h0, mra_qformer* h1, const int64_t* input_ids, const int64_t* attention_mask, const void* enc0,
+                             const void* enc1, int32_t items, int32_t L, int32_t kv0, int32_t kv1, float* out_query0, float* out_cls0,
+                             float* out_query1, float* out_cls1, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!h0 || !h1) return fail(MRA_EINVAL, "null handle");
+  if (h0 == h1) return fail(MRA_EINVAL, "the two lanes need two handles");
+  if (items < 0 || L < 0 || kv0 < 0 || kv1 < 0) return fail(MRA_EINVAL, "negative size");
+  if (items == 0) return MRA_OK;
+  mra_qformer* hs[2] = {h0, h1};
+  const void* encs[2] = {enc0, enc1};
+  const int kvs[2] = {kv0, kv1};
+  float* outq[2] = {out_query0, out_query1};
+  float* outc[2] = {out_cls0, out_cls1};
+  const mra_cfg& c = h0->cfg;
+  {
+    const mra_cfg& d = h1->cfg;
+    if (c.hidden != d.hidden || c.heads != d.heads || c.inter != d.inter || c.layers != d.layers || c.cross_freq != d.cross_freq || c.n_query != d.n_query ||
+        c.op_dtype != d.op_dtype || c.ln_eps != d.ln_eps || h0->device != h1->device)
+      return fail(MRA_EINVAL, "pair forward: the two Q-Formers must agree in hidden / heads / inter / layers / cross_freq / n_query / op_dtype and live on one device");
+  }
+  if (kv0 == 0 || kv1 == 0) return fail(MRA_EINVAL, "kv must be >= 1");
+  if (L > c.max_pos || L > h1->cfg.max_pos) return fail(MRA_EINVAL, "L exceeds max_pos");
+  if (!enc0 || !enc1 || (L > 0 && !input_ids)) return fail(MRA_EINVAL, "null input");
+  if ((out_cls0 || out_cls1) && L < 1) return fail(MRA_EINVAL, "out_cls needs L >= 1");
+  for (int l = 0; l < 2; ++l) {
+    if (!outq[l] && !outc[l]) return fail(MRA_EINVAL, "no output requested for a lane");
+    if (hs[l]->cross_precise) return fail(MRA_ESTATE, "pair forward runs the operand-dtype score chain: use mra_qformer_forward for split precision");
+    if (hs[l]->ncross > 0 && use_fold(hs[l], kvs[l]) && fold_streams(hs[l], kvs[l])) return fail(MRA_ESTATE, "pair forward: the streaming fold kernels are not supported");
+    char names[256];
+    const int miss = mra_qformer_missing(hs[l], names, sizeof(names));
+    int tolerated = 0;
+    for (const char* opt : {"ln.weight", "ln.bias", "llm_proj.weight", "llm_proj.bias"}) {
+      auto it = hs[l]->params.find(opt);
+      if (it != hs[l]->params.end() && !it->second.loaded) ++tolerated;
+    }
+    if (miss > tolerated) return fail(MRA_ESTATE, std::string("parameters not loaded: ") + names);
+  }
+  const size_t need = mra_qformer_pair_workspace_bytes(h0, h1, items, L, kv0, kv1);
+  if (!workspace || workspace_bytes < need) return fail(MRA_ENOMEM, "workspace too small: need " + std::to_string(need) + " bytes");
+  if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MRA_EINVAL, "workspace must be 256-byte aligned");
+
+  hipStream_t stream = as_stream(stream_);
+  const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
+  const int op = h0->op();
+  PairWork pw = layout_pair(h0, h1, (char*)workspace, N, L, kv0, kv1);
+  Work* w = pw.w;
+  const long long SH = (long long)S * H;
+  const size_t esz = 2;
+  const RowView all_rows = plain(N * S, H), all2 = plain(2 * N * S, H);
+  const RowView q_view = items_view(SH, Q, H);
+  const RowView t_view = items_view(SH, L > 0 ? L : 1, H);
+  const RowView cls_view = items_view(SH, 1, H);
+  const RowView qc_rows = plain(N * Q, H), qc2 = plain(2 * N * Q, H);
+  int rc;
+  bool fold[2];
+  for (int l = 0; l < 2; ++l) {
+    rc = launch_embed_ln((const long long*)input_ids, N, L, Q, H, hs[l]->cfg.vocab, hs[l]->query, 0, hs[l]->word, hs[l]->pos, hs[l]->embg, hs[l]->embb, c.ln_eps,
+                         w[l].hA32, w[l].hA16, nullptr, op, stream);
+    if (rc) return chk(rc, "embed_ln");
+    fold[l] = hs[l]->ncross > 0 && use_fold(hs[l], kvs[l]);
+    if (fold[l]) {
+      if (!fold_kmajor(hs[l])) {
+        const int kvp = fold_kvp(kvs[l]);
+        rc = launch_transpose_pad(encs[l], w[l].encT, kvs[l], hs[l]->cfg.enc_width, kvp, (long long)kvs[l] * hs[l]->cfg.enc_width, (long long)hs[l]->cfg.enc_width * kvp, N, op, stream);
+        if (rc) return chk(rc, "enc transpose");
+      }
+      if ((rc = mra_qformer_prepare(hs[l], stream_))) return rc;
+    } else if (hs[l]->ncross > 0) {
+      rc = kv_project(hs[l], encs[l], N, kvs[l], w[l].kv16, stream);
+      if (rc) return chk(rc, "kv projection gemm");
+    }
+  }
+  const long long* mask2 = nullptr;
+  if (attention_mask) {   // the two lanes share the prompt: their mask rows one after the other for the 2 N-item attention launch
+    HIP_TRY(hipMemcpyAsync(pw.mask2, attention_mask, (size_t)N * S * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(pw.mask2 + (size_t)N * S, attention_mask, (size_t)N * S * 8, hipMemcpyDeviceToDevice, stream));
+    mask2 = pw.mask2;
+  }
+  const bool ring = N * S >= 1024;
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW* Lw[2] = {&h0->layers[i], &h1->layers[i]};
+    const bool last = i == c.layers - 1;
+    // 1. Q | K | V of both lanes: two problems, one launch
+    {
+      GemmProb p[2] = {};
+      for (int l = 0; l < 2; ++l) {
+        p[l].A = w[l].hA16; p[l].a = all_rows; p[l].W = Lw[l]->wqkv; p[l].bias = Lw[l]->bqkv;
+        p[l].C = w[l].qkv16; p[l].c = plain(N * S, 3 * H); p[l].M = N * S; p[l].N = 3 * H; p[l].K = H;
+        p[l].tile_cfg = ring ? (((hs[l]->chain_ring & 1) && (3 * H) % 144 == 0) ? 9 : 2) : 0;
+      }
+      if ((rc = launch_gemm(p, 2, EPI_OP, op, stream))) return chk(rc, "qkv gemm (pair)");
+    }
+    // 2. self-attention of all 2 N items
+    {
+      AttnArgs a{};
+      a.Q = w[0].qkv16; a.K = w[0].qkv16 + (size_t)H * esz; a.V = w[0].qkv16 + (size_t)2 * H * esz; a.O = w[0].ctx16;
+      a.q_item_stride = (long long)S * 3 * H; a.q_ld = 3 * H;
+      a.k_item_stride = (long long)S * 3 * H; a.k_head_stride = 64; a.k_ld = 3 * H;
+      a.v_item_stride = (long long)S * 3 * H; a.v_head_stride = 64; a.v_ld = 3 * H;
+      a.o_item_stride = SH; a.o_ld = H;
+      a.mask = mask2; a.mask_ld = S;
+      a.items = 2 * N; a.heads = c.heads; a.q_rows = S; a.kv_len = S; a.scale = 0.125f; a.nsplit = 1; a.part = nullptr;
+      if ((rc = launch_attention(a, op, stream))) return chk(rc, "self attention (pair)");
+    }
+    // 3. output projections + residual (two problems), 4. LayerNorm of both lanes in one launch
+    {
+      GemmProb p[2] = {};
+      for (int l = 0; l < 2; ++l) {
+        p[l].A = w[l].ctx16; p[l].a = all_rows; p[l].W = Lw[l]->wo; p[l].bias = Lw[l]->bo; p[l].R = w[l].hA32; p[l].r = all_rows;
+        p[l].C = w[l].pre32; p[l].c = all_rows; p[l].M = N * S; p[l].N = H; p[l].K = H;
+        if ((hs[l]->chain_ring & 4) && ring && H % 96 == 0) p[l].tile_cfg = 11;
+      }
+      if ((rc = launch_gemm(p, 2, EPI_RES_F32, op, stream))) return chk(rc, "attn out gemm (pair)");
+      rc = launch_ln_rows4(w[0].pre32, all2, 2 * N * S, H, Lw[0]->ln1g, Lw[0]->ln1b, nullptr, nullptr, N * S, Lw[1]->ln1g, Lw[1]->ln1b, nullptr, nullptr, 1, 1,
+                           c.ln_eps, w[0].hB32, all2, w[0].hB16, all2, op, stream);
+      if (rc) return chk(rc, "attn ln (pair)");
+    }
+    const bool cross = Lw[0]->cross_index >= 0;
+    if (cross) {
+      // 5. cross query projections (two problems), 6. each lane's own cross-attention, 7. output projections + residual, 8. LayerNorm
+      GemmProb p[2] = {};
+      for (int l = 0; l < 2; ++l) {
+        p[l].A = w[l].hB16; p[l].a = q_view; p[l].W = Lw[l]->wcq; p[l].bias = Lw[l]->bcq;
+        p[l].C = w[l].qc16; p[l].c = qc_rows; p[l].M = N * Q; p[l].N = H; p[l].K = H;
+      }
+      if ((rc = launch_gemm(p, 2, EPI_OP, op, stream))) return chk(rc, "cross q gemm (pair)");
+      for (int l = 0; l < 2; ++l)
+        if ((rc = cross_core(hs[l], w[l], *Lw[l], encs[l], N, kvs[l], fold[l], false, false, stream))) return rc;
+      GemmProb o[2] = {};
+      for (int l = 0; l < 2; ++l) {
+        o[l].A = w[l].ctx16; o[l].a = qc_rows; o[l].W = Lw[l]->wco; o[l].bias = Lw[l]->bco; o[l].R = w[l].hB32; o[l].r = q_view;
+        o[l].C = w[l].pre32; o[l].c = qc_rows; o[l].M = N * Q; o[l].N = H; o[l].K = H;
+      }
+      if ((rc = launch_gemm(o, 2, EPI_RES_F32, op, stream))) return chk(rc, "cross out gemm (pair)");
+      // pre32 of lane l holds its compact [N*Q][H] rows at its own base: two launches would be needed for one row view; the rows of the two
+      // lanes are N*S*H apart, so address them as items of Q rows with an item stride that jumps lanes: view (item = lane): stride N*S*H, rpi N*Q
+      const RowView pre_v = items_view((long long)N * S * H, N * Q, H);
+      rc = launch_ln_rows4(w[0].pre32, pre_v, 2 * N * Q, H, Lw[0]->lncg, Lw[0]->lncb, nullptr, nullptr, N * Q, Lw[1]->lncg, Lw[1]->lncb, nullptr, nullptr, 1, 1,
+                           c.ln_eps, w[0].hC32, qc2, w[0].hC16, qc2, op, stream);
+      if (rc) return chk(rc, "cross ln (pair)");
+    }
+    // 9-14. feed-forwards: per lane a query problem and a text problem -> four problems per launch
+    int text_rows = 0;
+    RowView tv = t_view;
+    if (L > 0) {
+      if (!last) text_rows = N * L;
+      else if (outc[0] || outc[1]) { text_rows = N; tv = cls_view; }
+    }
+    const size_t t_off16 = (size_t)Q * H * esz, t_off32 = (size_t)Q * H;
+    const int ng = text_rows > 0 ? 4 : 2;
+    {
+      GemmProb g[4] = {};
+      for (int l = 0; l < 2; ++l) {
+        GemmProb& q = g[l];                 // query problems first (they decide the tile), then the text problems
+        q.A = cross ? (const void*)w[l].hC16 : (const void*)w[l].hB16; q.a = cross ? qc_rows : q_view;
+        q.W = Lw[l]->wiq; q.bias = Lw[l]->biq; q.C = w[l].ffn16; q.c = plain(N * Q, I); q.M = N * Q; q.N = I; q.K = H;
+        GemmProb& t = g[2 + l];
+        t.A = w[l].hB16 + t_off16; t.a = tv; t.W = Lw[l]->wit; t.bias = Lw[l]->bit;
+        t.C = w[l].ffn16 + (size_t)N * Q * I * esz; t.c = plain(text_rows, I); t.M = text_rows; t.N = I; t.K = H;
+      }
+      if ((h0->chain_ring & 2) && N * Q >= 512 && I % 192 == 0) g[0].tile_cfg = 10;
+      if ((rc = launch_gemm(g, ng, EPI_GELU_OP, op, stream))) return chk(rc, "ffn up gemm (pair)");
+    }
+    {
+      GemmProb g[4] = {};
+      for (int l = 0; l < 2; ++l) {
+        GemmProb& q = g[l];
+        q.A = w[l].ffn16; q.a = plain(N * Q, I); q.W = Lw[l]->woq; q.bias = Lw[l]->boq;
+        q.R = cross ? w[l].hC32 : w[l].hB32; q.r = cross ? qc_rows : q_view;
+        q.C = w[l].pre32; q.c = q_view; q.M = N * Q; q.N = H; q.K = I;
+        GemmProb& t = g[2 + l];
+        t.A = w[l].ffn16 + (size_t)N * Q * I * esz; t.a = plain(text_rows, I); t.W = Lw[l]->wot; t.bias = Lw[l]->bot;
+        t.R = w[l].hB32 + t_off32; t.r = tv; t.C = w[l].pre32 + t_off32; t.c = tv; t.M = text_rows; t.N = H; t.K = I;
+      }
+      g[0].tile_cfg = N * Q >= 512 && I % 128 == 0 ? 6 : 0;
+      if ((h0->chain_ring & 4) && N * Q >= 512 && H % 96 == 0) g[0].tile_cfg = 11;
+      if ((rc = launch_gemm(g, ng, EPI_RES_F32, op, stream))) return chk(rc, "ffn down gemm (pair)");
+    }
+    if (!last) {
+      if (text_rows == N * L && L > 0) {
+        // query / text LayerNorms of both lanes: four parameter sets, one launch over the 2 N S rows
+        rc = launch_ln_rows4(w[0].pre32, all2, 2 * N * S, H, Lw[0]->lnqg, Lw[0]->lnqb, Lw[0]->lntg, Lw[0]->lntb, N * S, Lw[1]->lnqg, Lw[1]->lnqb, Lw[1]->lntg,
+                             Lw[1]->lntb, S, Q, c.ln_eps, w[0].hA32, all2, w[0].hA16, all2, op, stream);
+        if (rc) return chk(rc, "ffn ln (pair)");
+      } else {   // L == 0: query rows only (the whole stream)
+        rc = launch_ln_rows4(w[0].pre32, all2, 2 * N * S, H, Lw[0]->lnqg, Lw[0]->lnqb, nullptr, nullptr, N * S, Lw[1]->lnqg, Lw[1]->lnqb, nullptr, nullptr, 1, 1,
+                             c.ln_eps, w[0].hA32, all2, w[0].hA16, all2, op, stream);
+        if (rc) return chk(rc, "ffn query ln (pair)");
+      }
+    } else {
+      for (int l = 0; l < 2; ++l) {   // last layer: LayerNorm straight into the caller's buffers
+        if (outq[l]) {
+          rc = launch_ln_rows(w[l].pre32, q_view, N * Q, H, Lw[l]->lnqg, Lw[l]->lnqb, c.ln_eps, outq[l], qc_rows, nullptr, qc_rows, op, stream);
+          if (rc) return chk(rc, "final query ln (pair)");
+        }
+        if (outc[l]) {
+          rc = launch_ln_rows(w[l].pre32 + t_off32, cls_view, N, H, Lw[l]->lntg, Lw[l]->lntb, c.ln_eps, outc[l], plain(N, H), nullptr, plain(N, H), op, stream);
+          if (rc) return chk(rc, "final cls ln (pair)");
         }
       }
     }

@@ -35,11 +35,15 @@ template <typename T, int NV>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const float* x, RowView xv, int rows, const float* gain,
                                                       const float* bias, float eps, float* y32, RowView y32v, T* y16,
                                                       RowView y16v, const float* gain2, const float* bias2, int period,
-                                                      int split) {
+                                                      int split, int lane_rows = 0x7fffffff, const float* gain3 = nullptr,
+                                                      const float* bias3 = nullptr, const float* gain4 = nullptr,
+                                                      const float* bias4 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  // two parameter sets in one launch: rows [split, period) of every item (the text rows) take the second one
+  // two parameter sets in one launch: rows [split, period) of every item (the text rows) take the second one; rows from lane_rows on
+  // (the second Q-Former of a pair forward) take sets 3 / 4 the same way
+  if (row >= lane_rows) { gain = gain3; bias = bias3; gain2 = gain4; bias2 = bias4; }
   if (gain2 && row % period >= split) { gain = gain2; bias = bias2; }
   constexpr int H = NV * 256;
   const float* xr = x + vrow(xv, row);
@@ -365,12 +369,20 @@ int launch_ln_rows(const float* x, RowView xv, int rows, int H, const float* gai
 int launch_ln_rows2(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2,
                     const float* bias2, int period, int split, float eps, float* y32, RowView y32v, void* y16, RowView y16v,
                     int op_dtype, hipStream_t stream) {
+  return launch_ln_rows4(x, xv, rows, H, gain, bias, gain2, bias2, 0x7fffffff, nullptr, nullptr, nullptr, nullptr, period, split, eps, y32, y32v,
+                         y16, y16v, op_dtype, stream);
+}
+
+int launch_ln_rows4(const float* x, RowView xv, int rows, int H, const float* gain, const float* bias, const float* gain2, const float* bias2,
+                    int lane_rows, const float* gain3, const float* bias3, const float* gain4, const float* bias4, int period, int split,
+                    float eps, float* y32, RowView y32v, void* y16, RowView y16v, int op_dtype, hipStream_t stream) {
   if (rows <= 0) return 0;
-  if (H % 256 || H > 1024 || H <= 0) return -1;
+  if (H % 256 || H > 1024 || H <= 0 || period <= 0) return -1;
+  if (lane_rows < rows && (!gain3 || !bias3)) return -1;
   const dim3 grid((rows + 3) / 4), block(256);
 #define MRA_LN_CASE(T, NV)                                                                                         \
   hipLaunchKernelGGL((ln_rows_kernel<T, NV>), grid, block, 0, stream, x, xv, rows, gain, bias, eps, y32, y32v, \
-                     (T*)y16, y16v, gain2, bias2, period, split)
+                     (T*)y16, y16v, gain2, bias2, period, split, lane_rows, gain3, bias3, gain4, bias4)
   const int nv = H / 256;
   if (op_dtype == OP_F16) {
     if (nv == 1) MRA_LN_CASE(f16, 1); else if (nv == 2) MRA_LN_CASE(f16, 2); else if (nv == 3) MRA_LN_CASE(f16, 3); else MRA_LN_CASE(f16, 4);

@@ -344,6 +344,46 @@ class QFormer(nn.Module):
                     check(lib().mra_qformer_set_kv_events(self._handle, None, None), "set_kv_events")
         return out
 
+    @staticmethod
+    def forward_pair(qf0: "QFormer", qf1: "QFormer", input_ids: Optional[torch.Tensor], attention_mask: Optional[torch.Tensor], enc0: torch.Tensor,
+                     enc1: torch.Tensor, want_cls: bool = True, kv_events=None):
+        """Both modality Q-Formers of a step in ONE launch sequence (``mra_qformer_forward_pair``): the layer chains as grouped launches,
+        each lane its own cross-attention.  enc0 / enc1 [N, Kv_l, E_l] in the operand dtype, the same prompt rows for both lanes.  Returns
+        ``[(query0, cls0), (query1, cls1)]`` (fp32; cls ``None`` without ``want_cls``).  ``kv_events``: (start, stop) pair for lane 0's
+        cross-layer-0 block (bench instrumentation)."""
+        qfs, encs = (qf0, qf1), []
+        for qf, enc in zip(qfs, (enc0, enc1)):
+            qf.sync_weights()
+            if enc.dim() != 3 or enc.shape[-1] != qf.cfg.enc_width:
+                raise MraError(f"encoder_hidden_states must be [N, Kv, {qf.cfg.enc_width}], got {tuple(enc.shape)}")
+            encs.append(enc.to(qf.cfg.op_dtype).contiguous())
+        N = int(encs[0].shape[0])
+        if int(encs[1].shape[0]) != N:
+            raise MraError("forward_pair: both lanes need the same number of items")
+        dev = encs[0].device
+        L = 0 if input_ids is None else int(input_ids.shape[1])
+        if input_ids is not None:
+            input_ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        if attention_mask is not None:
+            attention_mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        H, Q = qf0.cfg.hidden, qf0.cfg.n_query
+        outs = [(torch.empty(N, Q, H, dtype=torch.float32, device=dev), torch.empty(N, H, dtype=torch.float32, device=dev) if want_cls else None) for _ in qfs]
+        if N == 0:
+            return outs
+        with torch.cuda.device(qf0._device):
+            nbytes = (int(lib().mra_qformer_pair_workspace_bytes(qf0._handle, qf1._handle, N, L, int(encs[0].shape[1]), int(encs[1].shape[1]))) + 255) // 256 * 256
+            ws = qf0._workspace(nbytes)
+            if kv_events is not None:
+                check(lib().mra_qformer_set_kv_events(qf0._handle, kv_events[0].cuda_event, kv_events[1].cuda_event), "set_kv_events")
+            try:
+                check(lib().mra_qformer_forward_pair(qf0._handle, qf1._handle, ptr(input_ids), ptr(attention_mask), ptr(encs[0]), ptr(encs[1]), N, L,
+                                                     int(encs[0].shape[1]), int(encs[1].shape[1]), ptr(outs[0][0]), ptr(outs[0][1]), ptr(outs[1][0]), ptr(outs[1][1]),
+                                                     ptr(ws), nbytes, current_stream()), "mra_qformer_forward_pair")
+            finally:
+                if kv_events is not None:
+                    check(lib().mra_qformer_set_kv_events(qf0._handle, None, None), "set_kv_events")
+        return outs
+
     def llm_proj(self, z: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """A5: ``{modality}_llm_proj(last_hidden_state[:, :32, :])`` (reference ``:303``)."""
         cfg = self.cfg
@@ -362,6 +402,7 @@ class QFormer(nn.Module):
         (``mra_qformer_set_cross_mode``).  Same arithmetic, re-associated; the workspace size follows the mode."""
         code = {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4, "fold_rescale_pass": 5}.get(mode, mode)
         check(lib().mra_qformer_set_cross_mode(self._handle, int(code)), "mra_qformer_set_cross_mode")
+        self._cross_mode = mode if isinstance(mode, str) else {v: k for k, v in {"auto": 0, "kv_cache": 1, "fold": 2, "fold384": 3, "fold_stream": 4, "fold_rescale_pass": 5}.items()}.get(int(mode), "auto")
 
     def set_option(self, name: str, value: int) -> None:
         """Per-handle tuning option (``mra_qformer_set_option``), e.g. ``("chain_ring", mask)``."""
@@ -374,6 +415,7 @@ class QFormer(nn.Module):
         code = {"op": 0, "f16": 0, "split": 1}.get(mode, mode)
         with torch.cuda.device(self._device):
             check(lib().mra_qformer_set_cross_precision(self._handle, int(code)), "mra_qformer_set_cross_precision")
+        self._cross_precision = "split" if int(code) == 1 else "op"
 
     def flops(self, items: int, L: int, kv: int, with_last_text: bool) -> float:
         return float(lib().mra_qformer_flops(self._handle, items, L, kv, int(with_last_text)))

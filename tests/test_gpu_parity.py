@@ -473,3 +473,31 @@ def test_split_precision_chain_on_both_encoder_widths(video, audio, dev):
         assert e_split < Z_ATOL and e_split < 1.5 * e_base + 1e-3
         again = qf.forward_fused(ids.to(dev), att.to(dev), enc, want_full=True)["full"].cpu()   # back on the default path, same workspace
         assert torch.equal(again, base)
+
+
+def test_pair_forward_equals_the_two_separate_forwards(dev):
+    """``mra_qformer_forward_pair`` (both modality Q-Formers in one launch sequence: chain GEMMs grouped over the lanes, attention cores and
+    LayerNorms over 2 N items) against the two ``mra_qformer_forward`` calls it replaces -- same kernels, same summation order per lane:
+    a ragged prompt, Kv below / above the fold switch, the bench's chain shape (32 items), the sharded-style cls-only last layer."""
+    from mraudio_amd.models.xinstructblip import ENC_WIDTH, XInstructBLIP
+
+    model = XInstructBLIP(seed=5, perturb=True, device=dev)
+    for n, L, kvv, kva in ((5, 12, 300, 64), (3, 7, 2100, 40), (32, 32, 257, 256)):
+        g = torch.Generator().manual_seed(100 + n)
+        feats = {"video": torch.randn(n, kvv, ENC_WIDTH["video"], generator=g).half().to(dev), "audio": torch.randn(n, kva, ENC_WIDTH["audio"], generator=g).half().to(dev)}
+        ids = torch.randint(1000, 30000, (n, L), generator=g).to(dev)
+        tmask = torch.ones(n, L, dtype=torch.long, device=dev)
+        tmask[n // 2, L - 3:] = 0
+        outs = {}
+        for pair in (False, True):
+            model.pair_forward = pair
+            o = model.fuse_score(feats, ids, tmask, bs=1, num=n)
+            torch.cuda.synchronize()
+            outs[pair] = o
+        for m in ("video", "audio"):
+            dz = (outs[True]["z"][m] - outs[False]["z"][m]).abs().max().item()
+            dc = (outs[True]["cls"][m] - outs[False]["cls"][m]).abs().max().item()
+            assert dz <= 1e-5 and dc <= 1e-5, (n, m, dz, dc)
+        assert torch.equal(outs[True]["spans"], outs[False]["spans"])
+        assert (outs[True]["fused"] - outs[False]["fused"]).abs().max().item() <= 1e-6
+    model.pair_forward = False
