@@ -301,10 +301,11 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
 
     out = {}
     nframes, chunk = clips * frames_per_clip, clips * frames_per_clip   # every backend takes all frames of the step in one batched pass (its fastest setting)
-    for backend in ("hip", "hip_f16_residual", "torch"):
+    for backend in ("hip", "hip_separate_ln", "hip_f16_residual", "torch"):
         try:
             if backend.startswith("hip"):
-                vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev, residual="op" if backend.endswith("residual") else "fp32").eval().init_seeded_(0)
+                vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev, residual="op" if backend.endswith("residual") else "fp32",
+                                       ln_fold=backend != "hip_separate_ln").eval().init_seeded_(0)
             else:
                 with torch.device(dev):
                     vit = create_eva_vit_g(224, 0, False, "fp16").eval()
@@ -326,11 +327,12 @@ def time_encode(dev, clips, frames_per_clip, fuse_s):
             with torch.no_grad():
                 small = vit(x[pick])
             spot = (small.float() - y[pick].float()).abs().max().item()
-            spot_bar = 5e-2 if backend == "hip" else 5e-1     # 39 blocks: f16-rounded intermediates on |y| ~ 30 (f16 residual / stock f16: coarser)
+            spot_bar = 5e-2 if backend in ("hip", "hip_separate_ln") else 5e-1     # 39 blocks: f16-rounded intermediates on |y| ~ 30 (f16 residual / stock f16: coarser)
             if not spot < spot_bar:
                 raise FloatingPointError(f"{backend}: 4-frame spot check differs from the timed batch by {spot:.3e}")
             fl = vit.flops_per_frame() * nframes
-            out[backend] = {"what": ("EVA ViT-g/14 on mra_vit_forward (hand-written gfx950 kernels, f16 operands, fp32 residual)" if backend == "hip" else
+            out[backend] = {"what": ("EVA ViT-g/14 on mra_vit_forward (hand-written gfx950 kernels, f16 operands, fp32 residual, LayerNorms folded into the GEMMs around them)" if backend == "hip" else
+                                     "the same with the LayerNorms as separate launches (round 2's form; mra_vit_set_option ln_fold 0)" if backend == "hip_separate_ln" else
                                      "the same with the residual stream in f16 (every add rounds to 16 bits, as LAVIS' precision=\"fp16\" encoder does)" if backend == "hip_f16_residual" else
                                      "EVA ViT-g/14, stock PyTorch f16 (SDPA + hipBLASLt)") + f", random weights, {nframes} frames in chunks of {chunk}",
                             "ms": round(t * 1e3, 1), "tflops": round(fl / t / 1e12, 1), "gflop_per_frame": round(vit_gf(fl, nframes), 1),

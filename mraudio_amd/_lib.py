@@ -87,12 +87,14 @@ PROTOTYPES = {
     "mra_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "mra_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mra_vit_flops": (C.c_double, [C.c_void_p, C.c_int32]),
+    "mra_vit_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "mra_debug_gemm_launches": (C.c_int64, [C.c_int32, C.c_int32]),
 }
 
 # GemmFamily / GemmEpi codes of mra_debug_gemm_launches (csrc/kernels.h)
 GF_V1_64, GF_V1_128, GF_WS_256, GF_P8_256, GF_WS_128x384, GF_WS_176x384, GF_K128_64x128, GF_P8_TAIL, GF_P8_MIXED, GF_K128_64x64 = 0, 1, 3, 4, 5, 6, 7, 8, 9, 10
 EPI_OP, EPI_GELU_OP, EPI_RES_F32, EPI_F32, EPI_KV, EPI_SOFTPART, EPI_RES_OP = 0, 1, 2, 3, 4, 5, 8
+EPI_RES_F32_STAT, EPI_LNF_OP, EPI_LNF_GELU_OP = 10, 11, 12     # the ViT's folded LayerNorms (csrc/kernels.h)
 
 
 def gemm_launches(family: int, epi: int) -> int:

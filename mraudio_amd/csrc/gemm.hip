@@ -351,6 +351,39 @@ __device__ __forceinline__ void epilogue_softpart(const GemmProb& P, f32x4 (&acc
   }
 }
 
+// EPI_RES_F32_STAT: statistics of the FN * 16 = 128 columns a wave holds of each of its rows (row m = lane & 15 of fragment j: 32 values in
+// the lane, the rest in the three lanes with the same lane & 15): group mean and sum of squared deviations FROM THAT MEAN -- two passes over
+// registers, so nothing cancels however far the row's mean is from zero; groups are merged by launch_ln_group_stats (Chan et al.).
+template <int FN, int FM>
+__device__ __forceinline__ void group_stats(const GemmProb& P, f32x4 (&acc)[FN][FM], int n_base, int m_base, int lane) {
+  static_assert(FN == 8, "a wave's tile must be 128 columns wide");
+  const int lm = lane & 15;
+  const int groups = P.N >> 7, g = n_base >> 7;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / 128.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mean; q = __builtin_fmaf(d, d, q); }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const int m = m_base + j * 16 + lm;
+    if (lane < 16 && m < P.M) {
+      float2* dst = reinterpret_cast<float2*>(P.ln_y32) + ((long long)m * groups + g);
+      *dst = float2{mean, q};
+    }
+  }
+}
+
 // 16-bit outputs (EPI_OP, EPI_GELU_OP, EPI_KV) leave through LDS: a lane's natural store is 8 bytes
 // of one output row, 16 rows per wave instruction -- 32-byte fragments of 128-byte lines; measured on
 // the K/V projection that direct epilogue cost 23 k of the 105 k cycles of a 256x256 tile (store-issue
@@ -379,6 +412,15 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
       }
     }
   }
+  constexpr bool LNF = EPI == EPI_LNF_OP || EPI == EPI_LNF_GELU_OP;   // LayerNorm folded into this GEMM: see kernels.h
+  float mu[LNF ? FM : 1], rstd[LNF ? FM : 1];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const float2 st = reinterpret_cast<const float2*>(P.ln_y32)[min(m0 + wm0 + j * 16 + lm, P.M - 1)];
+      mu[j] = st.x; rstd[j] = st.y;
+    }
+  }
   if (stages)
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
@@ -386,12 +428,20 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (BIAS_FIRST) bv = bias4[i];
     else if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNF) cs = *reinterpret_cast<const f32x4*>(P.ln_gain + (n0 + nl < P.N ? n0 + nl : 0));
     const int hq = nl >> 6, d = nl & 63;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int ml = wm0 + j * 16 + lm;
-      f32x4 v = acc[i][j] + bv;
-      if constexpr (EPI == EPI_GELU_OP) {
+      f32x4 v;
+      if constexpr (LNF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rstd[j], __builtin_fmaf(-mu[j], cs[e], acc[i][j][e]), bv[e]);
+      } else {
+        v = acc[i][j] + bv;
+      }
+      if constexpr (EPI == EPI_GELU_OP || EPI == EPI_LNF_GELU_OP) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
@@ -788,7 +838,8 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   constexpr int WHALF = (TAIL ? 64 : 128) * ROWB, XHALF = (TAIL ? 256 : 128) * ROWB;   // half-tile sizes: W0, W1 | X0, X1
   constexpr int BUF = 2 * WHALF + 2 * XHALF;                                           // 64 KB (80 KB) per K tile
   constexpr int WP = WHALF / 8192, XP = XHALF / 8192;                                  // DMA instructions per wave and half-tile
-  constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP;
+  constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP || EPI == EPI_LNF_OP || EPI == EPI_LNF_GELU_OP;
+  constexpr bool RESF32 = EPI == EPI_RES_F32 || EPI == EPI_RES_F32_STAT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -839,7 +890,7 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   const int wrow = TAIL ? 0 : wr * 64 * ROWB, xrow = (TAIL ? wave : wc) * 32 * ROWB;   // this wave's rows inside a W / X half-tile
 
   f32x4 acc[FN][FM];
-  if constexpr (EPI == EPI_RES_F32) {
+  if constexpr (RESF32) {
     // issued BEFORE the prologue's DMA: older in the vmcnt order, so the prologue's vmcnt(6) covers them and their latency
     // overlaps the first half-tiles' (an ordinary load still pending inside the loop would make the compiler drain everything)
     accumulators_from_residual<FN, FM>(P, acc, n0 + (TAIL ? 0 : wr * WTN), m0 + (TAIL ? wave : wc) * WTM, lane);
@@ -967,6 +1018,15 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   if constexpr (STAGED) {
     __syncthreads();
     epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+  } else if constexpr (EPI == EPI_RES_F32_STAT) {
+    // the fp32 rows as EPI_RES_F32 stores them, the statistics of this wave's 128 columns of its 64 rows, then the same values once more in the
+    // operand dtype through LDS (whole 128-byte lines): what the LayerNorm launch behind this GEMM used to read back and write
+    epilogue<T, FN, FM, EPI_RES_F32, true>(P, acc, n0 + wn0, m0 + wm0, lane);
+    group_stats<FN, FM>(P, acc, n0 + wn0, m0 + wm0, lane);
+    __syncthreads();
+    GemmProb Q = P;
+    Q.C = P.ln_y16; Q.c = P.ln_y16v; Q.bias = nullptr;
+    epilogue_lds16<T, TN, TM, FN, FM, 512, EPI_OP>(Q, acc, smem, n0, m0, wn0, wm0, tid);
   } else {
     epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
@@ -1481,6 +1541,7 @@ int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false)
     switch (epi) {
       case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP, true>, a, 512, ldst, stream);
       case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32, true>, a, 512, ldst, stream);
+      case EPI_RES_F32_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_F32_STAT, true>, a, 512, ldst, stream);
       case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32, true>, a, 512, ldst, stream);
       default: return -2;
     }
@@ -1491,6 +1552,9 @@ int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false)
     case EPI_KV: return launch_k(gemm_p8_kernel<T, EPI_KV>, a, 512, lds, stream);
     case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP>, a, 512, lds, stream);
     case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32>, a, 512, lds, stream);
+    case EPI_RES_F32_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_F32_STAT>, a, 512, lds, stream);
+    case EPI_LNF_OP: return launch_k(gemm_p8_kernel<T, EPI_LNF_OP>, a, 512, lds, stream);
+    case EPI_LNF_GELU_OP: return launch_k(gemm_p8_kernel<T, EPI_LNF_GELU_OP>, a, 512, lds, stream);
     case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32>, a, 512, lds, stream);
     default: return -100;
   }
@@ -1579,6 +1643,7 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
       case EPI_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_OP>, a, 512, ldst, stream));   // the ViT's un-padded QKV (N = 4224)
       case EPI_RES_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream));
       case EPI_RES_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream));
+      case EPI_RES_F32_STAT: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32_STAT>, a, 512, ldst, stream));
       case EPI_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream));
       default: return -2;
     }
@@ -1685,7 +1750,14 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.pscale && (!p.w_ld || cfg != 4 || p.M > 384 || p.ps_ntiles <= 0 || p.K > p.ps_ntiles * 176 + 4 * 176)) return -1;   // M <= the 384-row tile (slices hold 512 rows)
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
-    if (epi == EPI_RES_F32 && (!p.R || p.r.rpi <= 0)) return -1;
+    if ((epi == EPI_RES_F32 || epi == EPI_RES_F32_STAT) && (!p.R || p.r.rpi <= 0)) return -1;
+    if (epi == EPI_RES_F32_STAT || epi == EPI_LNF_OP || epi == EPI_LNF_GELU_OP) {   // eight-phase tiles only, one plain problem
+      bool even = (p.K / 64) % 2 == 0 && p.K >= 128;
+      if (!(cfg == 2 && even && g_p8 && g_variant != 1) && !(cfg == 7 && epi == EPI_RES_F32_STAT)) return -1;
+      if (ngroups != 1 || p.batch > 1 || p.n_mask || p.n_ragged || !p.ln_y32) return -1;
+      if (epi == EPI_RES_F32_STAT && (p.N % 128 || !p.ln_y16 || p.ln_y16v.rpi <= 0 || (p.ln_y16v.ld & 7) || (p.ln_y16v.item_stride & 7) || (p.c.ld & 3) || (p.c.item_stride & 3))) return -1;
+      if (epi != EPI_RES_F32_STAT && (!p.ln_gain || (p.c.ld & 7) || (p.c.item_stride & 7))) return -1;
+    }
     if (epi == EPI_RES_LN && cfg != 10) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_RES_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores

@@ -23,6 +23,14 @@ enum GemmEpi {
                     // that finishes last (agent-scope counter GemmProb::ln_counter, one per row tile, zero before the launch, reset by the kernel)
                     // normalises the block's rows and writes ln_y32 / ln_y16 -- the reference's `LayerNorm(dense(x) + residual)` (HF:519-530,
                     // 573-587) in one launch.  C still receives the pre-LayerNorm rows (sc1 stores: other XCDs read them).
+  // LayerNorm folded into the GEMMs on either side of it (the ViT blocks, fp32 residual stream): y = LN(x) W^T + b with LN's gain inside
+  // W' = W diag(g) is  rstd[m] * (x W'^T - mu[m] * colsum(W')[n]) + (b + W beta)[n]  -- a GEMM over the op-dtype copy of the RAW rows x plus a
+  // rank-one correction in the epilogue.  The producer of x (a residual GEMM) emits that copy and the row statistics as it stores x:
+  EPI_RES_F32_STAT = 10,  // EPI_RES_F32, plus: ln_y16 (op dtype, row view ln_y16v) = the finished rows, and per (row, 128-column group) the
+                          // group mean and the group's sum of squared deviations, ln_y32[(m * (N / 128) + n / 128) * 2 + {0, 1}]
+                          // (launch_ln_group_stats folds the groups into (mean, rstd) per row).  Eight-phase tiles only (a wave owns 128 columns).
+  EPI_LNF_OP = 11,        // C(op dtype) = rstd[m] * (acc - mu[m] * ln_gain[n]) + bias[n]; (mu, rstd)[m] = ln_y32[2 m], ln_y32[2 m + 1]; ln_gain = colsum(W')
+  EPI_LNF_GELU_OP = 12,   // gelu_erf of the same (256 x 256 eight-phase tile only, both)
   EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile
                     // sum go to stat_m / stat_l [row][ntiles] (176 x 384 loader-wave tile only: a wave holds whole tile rows)
 };

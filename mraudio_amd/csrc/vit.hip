@@ -252,9 +252,80 @@ int pack_to(const void* src, void* dst, int op, long long rows_out, int cols_in,
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs around it (fp32 residual stream; kernels.h, EPI_RES_F32_STAT / EPI_LNF_*).  LN(x) W^T + b =
+// rstd (x W'^T - mu colsum(W')) + (b + W beta) with W' = W diag(gain): the QKV and fc1 GEMMs run on the op-dtype copy of the RAW rows that
+// the residual GEMM before them wrote next to its fp32 store, and finish the LayerNorm in their epilogue from (mu, rstd) per row.  What is
+// gone per block: two reads of the fp32 rows and two launches (94 us each at 256 frames: 5 % of the encoder).
+// ---------------------------------------------------------------------------------------------------------
+// W' = W diag(gain) in the operand dtype, cs[n] = sum_k W'[n][k] (of the ROUNDED W': what the MFMAs multiply), bf[n] = bias[n] + sum_k beta[k] W[n][k]
+template <typename T>
+__global__ void __launch_bounds__(256) vit_fold_weight_kernel(const T* W, const float* gain, const float* beta, const float* bias, T* Wf, float* cs,
+                                                              float* bf, int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const T* w = W + (long long)n * K;
+  T* wf = Wf + (long long)n * K;
+  float c = 0.f, b = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = (float)w[k];
+    const T f = from_f32<T>(wv * gain[k]);
+    wf[k] = f;
+    c += (float)f;
+    b = __builtin_fmaf(beta[k], wv, b);
+  }
+  c = wave_sum(c);
+  b = wave_sum(b);
+  if (lane == 0) { cs[n] = c; bf[n] = b + (bias ? bias[n] : 0.f); }
+}
+
+// groups[m][g] = (mean, sum of squared deviations) of 128 columns -> stats[m] = (mean, rstd) of the row (Chan et al.: equal counts)
+__global__ void __launch_bounds__(256) vit_group_stats_kernel(const float2* groups, long long M, int G, float eps, float2* stats) {
+  const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float2* g = groups + m * G;
+  float mean = 0.f;
+  for (int i = 0; i < G; ++i) mean += g[i].x;
+  mean /= (float)G;
+  float m2 = 0.f;
+  for (int i = 0; i < G; ++i) { const float d = g[i].x - mean; m2 += g[i].y + 128.f * d * d; }
+  stats[m] = float2{mean, 1.0f / sqrtf(m2 / (128.f * (float)G) + eps)};
+}
+
+// the rows the first block reads (patch embedding + positions): (mean, rstd) and the op-dtype copy; one wave per row, D = 128 k <= 2048
+template <typename T>
+__global__ void __launch_bounds__(256) vit_row_stats_kernel(const float* x, long long M, int D, float eps, float2* stats, T* x16) {
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float2* row = reinterpret_cast<const float2*>(x + m * D);
+  const int it = D >> 7;
+  float2 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    v[t] = t < it ? row[t * 64 + lane] : float2{0.f, 0.f};
+    s += v[t].x + v[t].y;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < it) { const float a = v[t].x - mean, b = v[t].y - mean; q += a * a + b * b; }
+  q = wave_sum(q);
+  if (lane == 0) stats[m] = float2{mean, 1.0f / sqrtf(q / (float)D + eps)};
+  T* o = x16 + m * D;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < it) { o[(t * 64 + lane) * 2] = from_f32<T>(v[t].x); o[(t * 64 + lane) * 2 + 1] = from_f32<T>(v[t].y); }
+}
+
 struct VitLayer {
   float *n1g, *n1b, *n2g, *n2b, *bqkv, *bproj, *bfc1, *bfc2;
   void *wqkv, *wproj, *wfc1, *wfc2;
+  // LayerNorm folded in (prepared by fold_weights): W diag(gain), its row sums, bias + W beta
+  void *wqkv_f, *wfc1_f;
+  float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1;
 };
 
 }  // namespace
@@ -272,7 +343,13 @@ struct mra_vit {
   bool tail_tile = true;   // N = dim GEMMs: full 256-wide tiles + a 128 x 512 tail tile per pair of row tiles (false: a masked sixth 256-wide column tile)
   int proj_tile = 3;   // GemmProb::tile_cfg of the N = dim GEMMs: 256 x 256 with a masked last column tile (1408 = 5.5 tiles); the exact-fit
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
+  // LayerNorms folded into the QKV / fc1 GEMMs (fp32 residual stream, dim = 256 k + 128): mra_vit_set_option("ln_fold", 0 / 1)
+  int ln_fold = 1;
+  bool fold_ready = false;   // W diag(gain) etc. are up to date with the loaded parameters
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
+  bool can_fold() const {
+    return cfg.residual_dtype == MRA_F32 && proj_tile == 3 && tail_tile && cfg.dim % 256 == 128 && cfg.dim > 128 && cfg.dim <= 2048 && cfg.mlp % 128 == 0;
+  }
 };
 
 namespace {
@@ -292,8 +369,27 @@ size_t vit_layout(mra_vit* h, char* base) {
     L.wproj = cv.take<char>(D * D, 2); L.bproj = cv.take<float>(D);
     L.wfc1 = cv.take<char>(I * D, 2); L.bfc1 = cv.take<float>(I);
     L.wfc2 = cv.take<char>(D * I, 2); L.bfc2 = cv.take<float>(D);
+    L.wqkv_f = cv.take<char>((size_t)h->nqkv * D, 2); L.cs_qkv = cv.take<float>(h->nqkv); L.bf_qkv = cv.take<float>(h->nqkv);
+    L.wfc1_f = cv.take<char>(I * D, 2); L.cs_fc1 = cv.take<float>(I); L.bf_fc1 = cv.take<float>(I);
   }
   return cv.off;
+}
+
+int fold_weights(mra_vit* h, hipStream_t st) {
+  const mra_vit_cfg& c = h->cfg;
+  const int D = c.dim, I = c.mlp;
+  for (auto& L : h->layers) {
+    if (h->op() == OP_F16) {
+      hipLaunchKernelGGL(vit_fold_weight_kernel<f16>, dim3((h->nqkv + 3) / 4), dim3(256), 0, st, (const f16*)L.wqkv, L.n1g, L.n1b, L.bqkv, (f16*)L.wqkv_f, L.cs_qkv, L.bf_qkv, h->nqkv, D);
+      hipLaunchKernelGGL(vit_fold_weight_kernel<f16>, dim3((I + 3) / 4), dim3(256), 0, st, (const f16*)L.wfc1, L.n2g, L.n2b, L.bfc1, (f16*)L.wfc1_f, L.cs_fc1, L.bf_fc1, I, D);
+    } else {
+      hipLaunchKernelGGL(vit_fold_weight_kernel<bf16>, dim3((h->nqkv + 3) / 4), dim3(256), 0, st, (const bf16*)L.wqkv, L.n1g, L.n1b, L.bqkv, (bf16*)L.wqkv_f, L.cs_qkv, L.bf_qkv, h->nqkv, D);
+      hipLaunchKernelGGL(vit_fold_weight_kernel<bf16>, dim3((I + 3) / 4), dim3(256), 0, st, (const bf16*)L.wfc1, L.n2g, L.n2b, L.bfc1, (bf16*)L.wfc1_f, L.cs_fc1, L.bf_fc1, I, D);
+    }
+  }
+  if (hipGetLastError() != hipSuccess) return -4;
+  h->fold_ready = true;
+  return 0;
 }
 
 int copy_f32(const void* src, int dtype, float* dst, long long n, hipStream_t st) {
@@ -391,7 +487,19 @@ int mra_vit_load(mra_vit* h, const char* name, const void* src, int32_t dtype, c
   } else return fail(MRA_ENAME, "unknown parameter name: " + key);
   if (rc) return chk(rc, "vit load");
   h->loaded[key] = 1;
+  h->fold_ready = false;
   return MRA_OK;
+}
+
+int mra_vit_set_option(mra_vit* h, const char* name, int32_t value) {
+  if (!h || !name) return fail(MRA_EINVAL, "null argument");
+  const std::string key(name);
+  if (key == "ln_fold") {
+    if (value != 0 && value != 1) return fail(MRA_EINVAL, "ln_fold: 0 or 1");
+    h->ln_fold = value;
+    return MRA_OK;
+  }
+  return fail(MRA_ENAME, "unknown option: " + key);
 }
 
 int mra_vit_missing(mra_vit* h) {
@@ -399,15 +507,25 @@ int mra_vit_missing(mra_vit* h) {
   return 4 + 13 * h->cfg.depth - (int)h->loaded.size();
 }
 
+namespace {
+// the wide buffer: patches, then Q|K|V, then the fc1 activation; with the residual stream in the operand dtype the fp32 embeddings
+// are staged behind the patches inside it, so it must also hold patches + M x dim x 4 (for small patches / large images that exceeds M x wide x 2)
+size_t vit_big_bytes(const mra_vit* h, size_t frames) {
+  const size_t M = frames * h->S;
+  const size_t wide = std::max<size_t>(std::max<size_t>(h->nqkv, h->cfg.mlp), h->kpad);
+  size_t big = M * wide * 2;
+  if (h->cfg.residual_dtype != MRA_F32) big = std::max(big, align_up(frames * h->np * h->np * h->kpad * 2) + M * h->cfg.dim * 4);
+  return big;
+}
+}  // namespace
+
 size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames) {
   if (!h || frames <= 0) return 0;
   const size_t M = (size_t)frames * h->S;
-  const size_t wide = std::max<size_t>(std::max<size_t>(h->nqkv, h->cfg.mlp), h->kpad);
-  // the wide buffer: patches, then Q|K|V, then the fc1 activation; with the residual stream in the operand dtype the fp32 embeddings
-  // are staged behind the patches inside it, so it must also hold patches + M x dim x 4 (for small patches / large images that exceeds M x wide x 2)
-  size_t big = M * wide * 2;
-  if (h->cfg.residual_dtype != MRA_F32) big = std::max(big, align_up((size_t)frames * h->np * h->np * h->kpad * 2) + M * h->cfg.dim * 4);
-  return align_up(M * h->cfg.dim * 2) + align_up(big) + 4096;
+  const size_t big = vit_big_bytes(h, (size_t)frames);
+  // folded LayerNorms: the op-dtype copy of the residual rows, the 128-column group statistics and (mean, rstd) per row
+  const size_t fold = h->can_fold() ? align_up(M * h->cfg.dim * 2) + align_up(M * (h->cfg.dim / 128) * 8) + align_up(M * 8) : 0;
+  return align_up(M * h->cfg.dim * 2) + align_up(big) + fold + 4096;
 }
 
 int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, void* out_, void* workspace, size_t workspace_bytes, void* stream_) {
@@ -464,15 +582,33 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
     attr_done |= 1ull << (h->device & 63);
   }
   const float sl2 = LOG2E / sqrtf((float)hd);
+  // folded LayerNorms (see vit_fold_weight_kernel): x16 = the op-dtype copy of the residual rows, groups = their 128-column statistics as the
+  // residual GEMMs leave them, rstat = (mean, rstd) per row for the QKV / fc1 epilogues
+  const bool fold = h->ln_fold && h->can_fold();
+  char* x16 = big + align_up(vit_big_bytes(h, (size_t)n));
+  float2* groups = reinterpret_cast<float2*>(x16 + align_up((size_t)M * D * 2));
+  float2* rstat = reinterpret_cast<float2*>(reinterpret_cast<char*>(groups) + align_up((size_t)M * (D / 128) * 8));
+  if (fold) {
+    if (!h->fold_ready && (rc = fold_weights(h, st))) return chk(rc, "vit LayerNorm fold of the weights");
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    if (op == OP_F16) hipLaunchKernelGGL(vit_row_stats_kernel<f16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (f16*)x16);
+    else hipLaunchKernelGGL(vit_row_stats_kernel<bf16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (bf16*)x16);
+  }
+  auto row_stats = [&]() {
+    hipLaunchKernelGGL(vit_group_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, groups, M, D / 128, c.ln_eps, rstat);
+  };
   for (int li = 0; li < c.depth; ++li) {
     const VitLayer& L = h->layers[li];
-    rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n1g, L.n1b, c.ln_eps, a16, op, st);
-    if (rc) return chk(rc, "vit ln1");
+    if (!fold) {
+      rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n1g, L.n1b, c.ln_eps, a16, op, st);
+      if (rc) return chk(rc, "vit ln1");
+    }
     {
       GemmProb p{};
-      p.A = a16; p.a = plain((int)M, D); p.W = L.wqkv; p.bias = L.bqkv;
+      p.A = fold ? x16 : a16; p.a = plain((int)M, D); p.W = fold ? L.wqkv_f : L.wqkv; p.bias = fold ? L.bf_qkv : L.bqkv;
       p.C = big; p.c = plain((int)M, h->nqkv); p.M = (int)M; p.N = h->nqkv; p.K = D;
-      rc = launch_gemm(&p, 1, EPI_OP, op, st);
+      if (fold) { p.ln_gain = L.cs_qkv; p.ln_y32 = reinterpret_cast<float*>(rstat); p.tile_cfg = 3; }
+      rc = launch_gemm(&p, 1, fold ? EPI_LNF_OP : EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
     if (S == 257) {   // ViT-g/224: the sequence length as a compile-time constant
@@ -484,29 +620,40 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
     }
     // x += A W^T + b for the two N = dim GEMMs.  dim = 1408 is 5.5 tiles of 256: GemmProb::tile_cfg 8 runs the five full column tiles
     // of two row tiles and then their last 128 columns as one 128 x 512 tile, all in one launch (a masked sixth 256-wide tile wastes 9 %)
-    auto residual_gemm = [&](const void* A, int K, const void* W, const float* bias) {
+    auto residual_gemm = [&](const void* A, int K, const void* W, const float* bias, bool stat) {
       GemmProb p{};
       p.A = A; p.a = plain((int)M, K); p.W = W; p.bias = bias;
       p.R = out; p.r = plain((int)M, D); p.C = x; p.c = plain((int)M, D); p.aux = x;
       p.M = (int)M; p.N = D; p.K = K; p.tile_cfg = h->proj_tile; p.n_mask = h->proj_tile == 3; p.order = 8;
-      const int epi = r16 ? EPI_RES_OP : EPI_RES_F32;
+      int epi = r16 ? EPI_RES_OP : EPI_RES_F32;
       const bool split = h->proj_tile == 3 && h->tail_tile && D % 256 == 128 && D > 128 && K % 128 == 0;
       if (split) { p.tile_cfg = 8; p.n_mask = 0; p.order = 0; }
+      if (stat) {   // the rows' op-dtype copy and group statistics for the folded LayerNorm behind this GEMM (can_fold() implies split)
+        p.ln_y32 = reinterpret_cast<float*>(groups); p.ln_y16 = x16; p.ln_y16v = plain((int)M, D);
+        epi = EPI_RES_F32_STAT;
+      }
       return launch_gemm(&p, 1, epi, op, st);
     };
-    rc = residual_gemm(a16, D, L.wproj, L.bproj);
+    rc = residual_gemm(a16, D, L.wproj, L.bproj, fold);
     if (rc) return chk(rc, "vit projection gemm");
-    rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
-    if (rc) return chk(rc, "vit ln2");
+    if (fold) {
+      row_stats();
+    } else {
+      rc = launch_modality_ln(x, xdt, nullptr, n, S, D, L.n2g, L.n2b, c.ln_eps, a16, op, st);
+      if (rc) return chk(rc, "vit ln2");
+    }
     {
       GemmProb p{};
-      p.A = a16; p.a = plain((int)M, D); p.W = L.wfc1; p.bias = L.bfc1;
+      p.A = fold ? x16 : a16; p.a = plain((int)M, D); p.W = fold ? L.wfc1_f : L.wfc1; p.bias = fold ? L.bf_fc1 : L.bfc1;
       p.C = big; p.c = plain((int)M, I); p.M = (int)M; p.N = I; p.K = D;
-      rc = launch_gemm(&p, 1, EPI_GELU_OP, op, st);
+      if (fold) { p.ln_gain = L.cs_fc1; p.ln_y32 = reinterpret_cast<float*>(rstat); p.tile_cfg = 3; }
+      rc = launch_gemm(&p, 1, fold ? EPI_LNF_GELU_OP : EPI_GELU_OP, op, st);
       if (rc) return chk(rc, "vit fc1 gemm");
     }
-    rc = residual_gemm(big, I, L.wfc2, L.bfc2);
+    const bool feeds_ln = fold && li + 1 < c.depth;   // the last block's rows are the output: nothing reads their copy
+    rc = residual_gemm(big, I, L.wfc2, L.bfc2, feeds_ln);
     if (rc) return chk(rc, "vit fc2 gemm");
+    if (feeds_ln) row_stats();
   }
   return hipGetLastError() == hipSuccess ? MRA_OK : fail(MRA_EHIP, "vit forward launch");
 }

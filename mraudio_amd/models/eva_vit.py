@@ -137,9 +137,11 @@ class HipEvaViTg(EvaViTg):
     container (state_dict keys unchanged); ``forward`` runs ALL given frames as one batched pass of hand-written gfx950
     kernels -- the four GEMMs per block on the eight-phase MFMA kernels with bias / GELU / residual fused, a 96-padded
     attention core -- and returns ``[n, 257, 1408]``: fp32 with the default fp32 residual stream, the operand dtype with
-    ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  No CPU path."""
+    ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  With the fp32 stream the
+    two LayerNorms of a block are folded into the GEMMs around them (``ln_fold``, ``mra_vit_set_option``; ``ln_fold=False`` runs them
+    as separate launches).  No CPU path."""
 
-    def __init__(self, *args, op_dtype: torch.dtype = torch.float16, residual: str = "fp32", device=None, **kw):
+    def __init__(self, *args, op_dtype: torch.dtype = torch.float16, residual: str = "fp32", device=None, ln_fold: bool = True, **kw):
         super().__init__(*args, **kw)
         import ctypes as C
 
@@ -159,6 +161,12 @@ class HipEvaViTg(EvaViTg):
             _lib.check(_lib.lib().mra_vit_create(C.byref(cfg), C.byref(self._handle)), "mra_vit_create")
         self._dirty, self._ws = True, None
         self.to(self._device)
+        if not ln_fold:
+            self.set_option("ln_fold", 0)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle switch of the HIP encoder (``mra_vit_set_option``): ``"ln_fold"`` 0 / 1."""
+        self._lib.check(self._lib.lib().mra_vit_set_option(self._handle, name.encode(), int(value)), f"mra_vit_set_option({name})")
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)

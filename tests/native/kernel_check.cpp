@@ -415,6 +415,100 @@ static void test_gemm_res_ln(int op, int M, int N, int K, int groups) {
   for (auto p : dB) delete p; for (auto p : dR) delete p; for (auto p : dC) delete p; for (auto p : dY32) delete p; for (auto p : dG) delete p; for (auto p : dBe) delete p;
 }
 
+// LayerNorm folded into the GEMMs around it (EPI_RES_F32_STAT -> group statistics -> EPI_LNF_*): producer x = A1 W1^T + b1 + R with the
+// op-dtype copy and the 128-column group statistics; then y = LN(x; gain, beta) W2^T + b2 computed as the consumer GEMM over the raw copy
+// with W2 diag(gain), its row sums and b2 + W2 beta (prepared here on the host exactly as vit_fold_weight_kernel does).  Reference in double:
+// the explicit LayerNorm of the fp32 rows, then the product with the UNfolded W2.
+static void test_gemm_ln_fold(int op, int M, int D, int K1, int N2, bool gelu, float offset) {
+  std::vector<uint16_t> A1((size_t)M * K1), W1((size_t)D * K1), W2((size_t)N2 * D), W2f((size_t)N2 * D);
+  for (auto& v : A1) v = to_op(frand(), op);
+  for (auto& v : W1) v = to_op(frand(0.05f), op);
+  for (auto& v : W2) v = to_op(frand(0.05f), op);
+  std::vector<float> b1(D), R((size_t)M * D), gain(D), beta(D), b2(N2), cs(N2), bf(N2);
+  for (auto& v : b1) v = frand(0.5f);
+  for (auto& v : R) v = offset + frand(2.f);      // offset: a row mean far from zero (the case a sum / sum-of-squares formulation would lose)
+  for (auto& v : gain) v = 1.f + frand(0.3f);
+  for (auto& v : beta) v = frand(0.2f);
+  for (auto& v : b2) v = frand(0.5f);
+  for (int n = 0; n < N2; ++n) {
+    float c = 0.f, b = 0.f;
+    for (int k = 0; k < D; ++k) {
+      const float w = from_op(W2[(size_t)n * D + k], op);
+      W2f[(size_t)n * D + k] = to_op(w * gain[k], op);
+      c += from_op(W2f[(size_t)n * D + k], op);
+      b += beta[k] * w;
+    }
+    cs[n] = c; bf[n] = b + b2[n];
+  }
+  const int G = D / 128;
+  Dev<uint16_t> dA1(A1), dW1(W1), dW2f(W2f), dX16((size_t)M * D), dY((size_t)M * N2);
+  Dev<float> dB1(b1), dR(R), dX((size_t)M * D), dGroups((size_t)M * G * 2), dStat((size_t)M * 2), dCs(cs), dBf(bf);
+  dX16.fill(0xFF); dGroups.fill(0xFF);
+  GemmProb p;
+  memset(&p, 0, sizeof(p));
+  p.A = dA1.p; p.a = RowView{0, M, K1}; p.W = dW1.p; p.bias = dB1.p; p.R = dR.p; p.r = RowView{0, M, D};
+  p.C = dX.p; p.c = RowView{0, M, D}; p.M = M; p.N = D; p.K = K1; p.tile_cfg = D % 256 ? 8 : 3;
+  p.ln_y32 = dGroups.p; p.ln_y16 = dX16.p; p.ln_y16v = RowView{0, M, D};
+  int rc = launch_gemm(&p, 1, EPI_RES_F32_STAT, op, 0);
+  CK(hipDeviceSynchronize());
+  // the group statistics -> (mean, rstd) per row: host restatement of vit_group_stats_kernel (the kernel itself is exercised by the ViT tests)
+  std::vector<float> groups = dGroups.get(), x = dX.get();
+  std::vector<uint16_t> x16 = dX16.get();
+  std::vector<float> stat((size_t)M * 2);
+  double worst = rc ? 1e30 : 0, worst_stat = 0;
+  const float eps = 1e-6f;
+  for (int m = 0; m < M && !rc; ++m) {
+    float mean = 0.f, m2 = 0.f;
+    for (int g = 0; g < G; ++g) mean += groups[((size_t)m * G + g) * 2];
+    mean /= G;
+    for (int g = 0; g < G; ++g) { const float d = groups[((size_t)m * G + g) * 2] - mean; m2 += groups[((size_t)m * G + g) * 2 + 1] + 128.f * d * d; }
+    stat[(size_t)m * 2] = mean; stat[(size_t)m * 2 + 1] = 1.0f / sqrtf(m2 / D + eps);
+    double dm = 0, dv = 0;
+    for (int n = 0; n < D; ++n) dm += x[(size_t)m * D + n];
+    dm /= D;
+    for (int n = 0; n < D; ++n) dv += (x[(size_t)m * D + n] - dm) * (x[(size_t)m * D + n] - dm);
+    worst_stat = std::max(worst_stat, fabs(mean - dm) / (1 + fabs(dm)));
+    worst_stat = std::max(worst_stat, fabs(stat[(size_t)m * 2 + 1] - 1.0 / sqrt(dv / D + eps)) * sqrt(dv / D + eps));
+    for (int n = 0; n < D; ++n) {
+      double acc = b1[n] + R[(size_t)m * D + n];
+      for (int k = 0; k < K1; ++k) acc += (double)from_op(A1[(size_t)m * K1 + k], op) * from_op(W1[(size_t)n * K1 + k], op);
+      worst = std::max(worst, fabs(x[(size_t)m * D + n] - acc) / (1 + fabs(acc)));
+      if (x16[(size_t)m * D + n] != to_op(x[(size_t)m * D + n], op)) worst = 1e30;   // the copy is the stored fp32 value rounded once
+    }
+  }
+  char name[160];
+  snprintf(name, sizeof(name), "gemm residual + op-dtype copy + group statistics %s M%d N%d K%d offset %.0f", op == OP_F16 ? "f16" : "bf16", M, D, K1, offset);
+  report(name, std::max(worst, worst_stat * 10), 2e-4);
+  if (rc) return;
+  Dev<float> dSt(stat);
+  GemmProb q;
+  memset(&q, 0, sizeof(q));
+  q.A = dX16.p; q.a = RowView{0, M, D}; q.W = dW2f.p; q.bias = dBf.p; q.C = dY.p; q.c = RowView{0, M, N2}; q.M = M; q.N = N2; q.K = D; q.tile_cfg = 3;
+  q.ln_gain = dCs.p; q.ln_y32 = dSt.p;
+  rc = launch_gemm(&q, 1, gelu ? EPI_LNF_GELU_OP : EPI_LNF_OP, op, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> y = dY.get();
+  worst = rc ? 1e30 : 0;
+  std::vector<double> ln(D);
+  for (int m = 0; m < M && !rc; ++m) {
+    double dm = 0, dv = 0;
+    for (int n = 0; n < D; ++n) dm += x[(size_t)m * D + n];
+    dm /= D;
+    for (int n = 0; n < D; ++n) dv += (x[(size_t)m * D + n] - dm) * (x[(size_t)m * D + n] - dm);
+    const double rstd = 1.0 / sqrt(dv / D + eps);
+    for (int n = 0; n < D; ++n) ln[n] = (x[(size_t)m * D + n] - dm) * rstd * gain[n] + beta[n];
+    for (int n = 0; n < N2; ++n) {
+      double acc = b2[n];
+      for (int k = 0; k < D; ++k) acc += ln[k] * from_op(W2[(size_t)n * D + k], op);
+      if (gelu) acc = 0.5 * acc * (1.0 + erf(acc * 0.70710678118654752440));
+      worst = std::max(worst, fabs(from_op(y[(size_t)m * N2 + n], op) - acc) / (1 + fabs(acc)));
+    }
+  }
+  snprintf(name, sizeof(name), "gemm with the LayerNorm folded in (%s) %s M%d N%d K%d offset %.0f", gelu ? "GELU" : "plain", op == OP_F16 ? "f16" : "bf16", M, N2, D, offset);
+  // operands: raw rows and W diag(gain) rounded to the operand dtype (the separate-LayerNorm form rounds LN(x) and W instead): same order of error
+  report(name, worst, op == OP_F16 ? 4e-3 * (1 + offset / 4) : 3e-2 * (1 + offset / 4));
+}
+
 // n_mask: N not a multiple of the tile, plain [M][N] output rows; columns past N are neither read (bias, residual) nor stored
 static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K);
@@ -1127,6 +1221,10 @@ int main(int argc, char** argv) {
   test_gemm(6, EPI_F32, OP_BF16, 1000, 128, 128, false);
   test_gemm(6, EPI_RES_OP, OP_F16, 700, 128, 1408, true);
   test_gemm(6, EPI_RES_F32, OP_F16, 512, 128, 6144, false);
+  test_gemm_ln_fold(OP_F16, 700, 384, 256, 512, false, 0.f);      // LayerNorm folded into the producer / consumer GEMMs: mixed tiles (N = 256 k + 128), ragged M
+  test_gemm_ln_fold(OP_F16, 1300, 1408, 128, 256, true, 0.f);      // the ViT's width: 11 groups, odd number of row tiles, GELU consumer
+  test_gemm_ln_fold(OP_F16, 520, 640, 384, 256, false, 8.f);       // row means 8 sigma from zero
+  test_gemm_ln_fold(OP_BF16, 600, 512, 128, 512, true, 0.f);       // N = 256 k: full tiles only (tile_cfg 3)
   test_gemm(7, EPI_RES_F32, OP_F16, 1300, 384, 256, true);         // tile_cfg 8: 256-wide tiles + 128 x 512 tail tiles in one launch; odd number of row tiles
   test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);

@@ -52,6 +52,18 @@ def test_hip_vit_matches_the_hf_vectors_and_the_fp32_restatement(pair, golden_di
     more = torch.cat([make_frames(3, seed=21), frames])
     ym = hip(more.to(dev)).cpu()
     assert (ym[3:] - y).abs().max().item() < 1e-4
+    # the default folds the LayerNorms into the GEMMs around them; with separate LayerNorm launches (round 2's form) the same bars hold, and
+    # the two forms differ from each other by less than either differs from the fp32 restatement
+    hip.set_option("ln_fold", 0)
+    try:
+        y0 = hip(frames.to(dev)).cpu()
+    finally:
+        hip.set_option("ln_fold", 1)
+    rel0 = ((y0 - want).norm() / want.norm()).item()
+    print(f"vit depth {DEPTH}: rel error folded LayerNorms {rel:.3e}, separate LayerNorm launches {rel0:.3e}, one against the other {((y - y0).norm() / want.norm()).item():.3e}")
+    assert (y0 - want).abs().max().item() < 2e-2 and rel0 < 2e-3, rel0
+    assert np.abs(y0[:, ROWS].numpy() - gold["rows"]).max() < 2e-2
+    assert ((y - y0).norm() / want.norm()).item() < 2e-3
 
 
 def test_hip_vit_with_the_reference_precision_residual(pair, dev):
@@ -135,7 +147,14 @@ def _launches():
     from mraudio_amd import _lib as L
 
     return {"qkv": L.gemm_launches(L.GF_P8_256, L.EPI_OP), "fc1": L.gemm_launches(L.GF_P8_256, L.EPI_GELU_OP),
-            "res32": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_F32), "res16": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_OP)}
+            "res32": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_F32), "res16": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_OP),
+            # the folded-LayerNorm forms (default with the fp32 residual stream)
+            "qkv_f": L.gemm_launches(L.GF_P8_256, L.EPI_LNF_OP), "fc1_f": L.gemm_launches(L.GF_P8_256, L.EPI_LNF_GELU_OP),
+            "res32_s": L.gemm_launches(L.GF_P8_MIXED, L.EPI_RES_F32_STAT)}
+
+
+def _delta(before, after):
+    return {k: after[k] - before[k] for k in after if after[k] != before[k]}
 
 
 @pytest.fixture(scope="module")
@@ -153,18 +172,33 @@ def depth2(dev):
     return ref, hips, frames, want
 
 
-@pytest.mark.parametrize("residual", ["fp32", "op"])
+@pytest.mark.parametrize("residual", ["fp32", "fp32-separate-ln", "op"])
 def test_eight_phase_gemms_of_the_shipped_library_at_32_frames(depth2, dev, residual):
-    """32 frames = 8224 rows = 33 row tiles: QKV (594 tiles) and fc1 + GELU (792 tiles) run on ``gemm_p8_kernel<EPI_OP>`` /
-    ``<EPI_GELU_OP>`` of the SHIPPED library (launch counters), projection / fc2 on ``gemm_p8_mixed_kernel``; an odd number of row
-    tiles, a ragged last one.  Against the fp32 CPU restatement at the bars of the small-batch tests."""
+    """32 frames = 8224 rows = 33 row tiles: QKV (594 tiles) and fc1 + GELU (792 tiles) run on ``gemm_p8_kernel`` of the SHIPPED
+    library (launch counters), projection / fc2 on ``gemm_p8_mixed_kernel``; an odd number of row tiles, a ragged last one.  With the
+    fp32 residual stream the default epilogues are the folded-LayerNorm ones (``EPI_LNF_OP`` / ``EPI_LNF_GELU_OP`` behind
+    ``EPI_RES_F32_STAT``; the last block's fc2 feeds no LayerNorm and stays ``EPI_RES_F32``); ``fp32-separate-ln`` runs round 2's form
+    (``EPI_OP`` / ``EPI_GELU_OP`` / ``EPI_RES_F32`` + LayerNorm launches).  Against the fp32 CPU restatement at the bars of the small-batch tests."""
     ref, hips, frames, want = depth2
-    before = _launches()
-    y = hips[residual](frames.to(dev)).float().cpu()
-    after = _launches()
-    assert after["qkv"] - before["qkv"] == 2 and after["fc1"] - before["fc1"] == 2, (before, after)   # one per block
-    key = "res32" if residual == "fp32" else "res16"
-    assert after[key] - before[key] == 4, (before, after)
+    separate = residual == "fp32-separate-ln"
+    residual = residual.split("-")[0]
+    hip = hips[residual]
+    if separate:
+        hip.set_option("ln_fold", 0)
+    try:
+        before = _launches()
+        y = hip(frames.to(dev)).float().cpu()
+        after = _launches()
+    finally:
+        if separate:
+            hip.set_option("ln_fold", 1)
+    if residual == "op":
+        expect = {"qkv": 2, "fc1": 2, "res16": 4}                     # one per block; two residual GEMMs per block
+    elif separate:
+        expect = {"qkv": 2, "fc1": 2, "res32": 4}
+    else:
+        expect = {"qkv_f": 2, "fc1_f": 2, "res32_s": 3, "res32": 1}
+    assert _delta(before, after) == expect, (_delta(before, after), expect)
     assert torch.isfinite(y).all()
     err, rel = (y - want).abs().max().item(), ((y - want).norm() / want.norm()).item()
     print(f"vit 32 frames depth 2 residual {residual}: max|d| {err:.3e} rel {rel:.3e} on |y| max {want.abs().max().item():.2f}")
@@ -179,7 +213,7 @@ def test_benchmarked_batch_of_1024_frames(depth2, dev):
     """The batch bench.py times: 1024 frames = 263 168 rows (1028 row tiles, 18.5 k / 24.7 k tiles per launch, the XCD remap and the
     ``order = 8`` walk at full size, 514 pairs of row tiles for the tail tile).  Frames = a 4-frame base tiled 256 times, so every row
     of the big batch must reproduce the 32-frame batch (same kernels, same accumulation order: bit for bit) and, within the f16
-    rounding of the intermediate activations, the 4-frame batch (which runs the 128 x 128 two-buffer tiles instead)."""
+    rounding of the intermediate activations, the 4-frame batch."""
     ref, hips, frames, want = depth2
     hip = hips["fp32"]
     base = frames[:4].to(dev).half()
@@ -188,7 +222,7 @@ def test_benchmarked_batch_of_1024_frames(depth2, dev):
     before = _launches()
     big = hip(base.repeat(256, 1, 1, 1))
     after = _launches()
-    assert after["qkv"] - before["qkv"] == 2 and after["fc1"] - before["fc1"] == 2 and after["res32"] - before["res32"] == 4
+    assert _delta(before, after) == {"qkv_f": 2, "fc1_f": 2, "res32_s": 3, "res32": 1}, _delta(before, after)
     assert big.shape == (1024, 257, 1408) and torch.isfinite(big).all()
     big = big.view(256, 4, 257, 1408)
     d32 = max((big[i] - y32[:4]).abs().max().item() for i in range(256))
@@ -196,7 +230,7 @@ def test_benchmarked_batch_of_1024_frames(depth2, dev):
     dself = (y32.view(8, 4, 257, 1408) - y32[:4]).abs().max().item()
     print(f"vit 1024 frames: max|d| vs the 32-frame batch {d32:.3e} (32-frame batch vs itself {dself:.3e}), vs the 4-frame batch {d4:.3e}")
     assert d32 <= 1e-5 and dself <= 1e-5          # same kernels: position in the batch must not matter
-    assert d4 <= 1e-4                             # other tile kernels (128 x 128 two-buffer loop), same K order: measured 0.0 on MI355X (r03a)
+    assert d4 <= 1e-4                             # same K order whatever the batch: measured 0.0 on MI355X (r03a)
     w4 = want[:4]
     assert (big[255].cpu() - w4).abs().max().item() < 2e-2 and (big[128].cpu() - w4).abs().max().item() < 2e-2   # and it is the right answer
 
@@ -215,7 +249,9 @@ def test_full_depth_39_blocks_against_the_hf_fixture(dev, golden_dir):
     report = {}
     hip = HipEvaViTg(depth=FULL_DEPTH, device=dev, residual="fp32").eval().init_seeded_(FULL_WEIGHT_SEED)
     sd = hip.state_dict()
-    for residual in ("fp32", "op"):
+    for residual in ("fp32", "fp32-separate-ln", "op"):
+        if residual == "fp32-separate-ln":
+            hip.set_option("ln_fold", 0)
         if residual == "op":
             del hip
             torch.cuda.empty_cache()
@@ -233,6 +269,9 @@ def test_full_depth_39_blocks_against_the_hf_fixture(dev, golden_dir):
     # (depth 3: 2e-2 / 2e-3 bars on |y| <= 7 -- the relative error does NOT grow with depth: rounding errors of the f16 operands are
     # independent per block and the stream's norm grows as fast as they accumulate); f16 residual (78 rounded adds) max|d| 7.2e-2,
     # rel 1.9e-3.  Bars = 2 x measured.
-    assert report["fp32"]["max_abs"] < 4e-2 and report["fp32"]["rel"] < 1.6e-3, report
+    # The default fp32 form (LayerNorms folded into the GEMMs: raw rows and W diag(gain) rounded to f16 instead of LN(x) and W) is held to the
+    # SAME bars as the separate-LayerNorm form they were measured on.
+    for k in ("fp32", "fp32-separate-ln"):
+        assert report[k]["max_abs"] < 4e-2 and report[k]["rel"] < 1.6e-3 and report[k]["token_sq_rel"] < 3e-4, report
     assert report["op"]["max_abs"] < 1.5e-1 and report["op"]["rel"] < 4e-3, report
-    assert report["fp32"]["token_sq_rel"] < 3e-4 and report["op"]["token_sq_rel"] < 8e-4, report
+    assert report["op"]["token_sq_rel"] < 8e-4, report
