@@ -11,7 +11,8 @@
 // 97 % of the flops are the four GEMMs per block at M = frames x 257 rows: the eight-phase 256 x 256 kernel of gemm.hip (QKV, fc1;
 // the N = 1408 ones as full tiles plus a 128 x 512 tail tile per pair of row tiles, GemmProb::tile_cfg 8) with bias / GELU /
 // residual fused: the residual GEMMs START their accumulators at bias + residual, so their epilogue only stores.  The fp32
-// residual stream is updated in place and IS the output; LayerNorms write the f16 operand of the next GEMM.
+// residual stream is updated in place and IS the output.  LayerNorms: folded into the GEMMs on either side (default with the fp32 stream,
+// see vit_fold_weight_kernel below) or separate launches that write the f16 operand of the next GEMM (f16 stream; ln_fold 0).
 // Head dimension 88 is not a multiple of the MFMA K step: the QKV weight is regrouped [q|k|v][head][96] with eight zero rows
 // per head, so Q, K, V come out of the GEMM padded to 96 and the attention core (vit_attn_kernel below) runs on 3 x 32-deep
 // MFMA steps; the zero columns add nothing to any dot product.  (Round 3 measured the alternative -- Q | K | V un-padded out of the
