@@ -395,11 +395,27 @@ __device__ __forceinline__ void group_stats(const GemmProb& P, f32x4 (&acc)[FN][
 // BIAS_FIRST: all FN bias pieces in one round trip before the staging loop (a load per fragment next to its use is one round trip
 // per fragment); only on the small tiles: with 128 accumulators live the extra 4 FN registers spill (650-800 bytes per lane at the loader-wave
 // kernels' 168-register budget, 300-350 in the eight-phase kernel).
-template <typename T, int TN, int TM, int FN, int FM, int NT, int EPI, bool BIAS_FIRST = false>
+// BIAS_LDS (the eight-phase tiles: 128 accumulators per lane, no room for FN bias pieces): the tile's TN bias values (and the folded LayerNorm's
+// column sums) are fetched by TN threads in ONE round trip into LDS behind the staged tile (smem needs TN * TM * 2 + 8 TN bytes) and read from
+// there per fragment.  Next to their use -- one conditional load per fragment, closed by vmcnt(0) -- they were eight serial L2 round trips
+// per tile (the ISA showed `s_cbranch_execz; global_load; s_waitcnt vmcnt(0)` eight times in a row).
+template <typename T, int TN, int TM, int FN, int FM, int NT, int EPI, bool BIAS_FIRST = false, bool BIAS_LDS = false>
 __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[FN][FM], char* smem, int n0, int m0, int wn0,
                                                int wm0, int tid, bool stages = true) {   // stages == false (wave-uniform): this wave owns no accumulators, it only helps copying out
   const int lane = tid & 63;
   const int lm = lane & 15, ln = (lane >> 4) * 4;
+  static_assert(!(BIAS_FIRST && BIAS_LDS), "one way to fetch the bias");
+  float* sbias = reinterpret_cast<float*>(smem + TN * TM * 2);   // [TN] bias, then [TN] column sums (BIAS_LDS)
+  if constexpr (BIAS_LDS) {
+    static_assert(TN <= NT, "one value per thread");
+    if (tid < TN) {
+      const int n = min(n0 + tid, P.N - 1);
+      float b = P.bias ? P.bias[n] : 0.f;
+      if (n0 + tid >= P.N) b = 0.f;
+      sbias[tid] = b;
+      if constexpr (EPI == EPI_LNF_OP || EPI == EPI_LNF_GELU_OP) sbias[TN + tid] = P.ln_gain[n];
+    }
+  }
   f32x4 bias4[BIAS_FIRST ? FN : 1];
   if constexpr (BIAS_FIRST) {
 #pragma unroll
@@ -421,15 +437,20 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
       mu[j] = st.x; rstd[j] = st.y;
     }
   }
+  if constexpr (BIAS_LDS) __syncthreads();
   if (stages)
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int nl = wn0 + i * 16 + ln;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (BIAS_FIRST) bv = bias4[i];
+    else if constexpr (BIAS_LDS) bv = *reinterpret_cast<const f32x4*>(sbias + nl);
     else if (P.bias && n0 + nl < P.N) bv = *reinterpret_cast<const f32x4*>(P.bias + n0 + nl);
     f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (LNF) cs = *reinterpret_cast<const f32x4*>(P.ln_gain + (n0 + nl < P.N ? n0 + nl : 0));
+    if constexpr (LNF) {
+      if constexpr (BIAS_LDS) cs = *reinterpret_cast<const f32x4*>(sbias + TN + nl);
+      else cs = *reinterpret_cast<const f32x4*>(P.ln_gain + (n0 + nl < P.N ? n0 + nl : 0));
+    }
     const int hq = nl >> 6, d = nl & 63;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -1017,7 +1038,7 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   const int wn0 = TAIL ? 0 : wr * WTN, wm0 = (TAIL ? wave : wc) * WTM;
   if constexpr (STAGED) {
     __syncthreads();
-    epilogue_lds16<T, TN, TM, FN, FM, 512, EPI>(P, acc, smem, n0, m0, wn0, wm0, tid);
+    epilogue_lds16<T, TN, TM, FN, FM, 512, EPI, false, true>(P, acc, smem, n0, m0, wn0, wm0, tid);
   } else if constexpr (EPI == EPI_RES_F32_STAT) {
     // the fp32 rows as EPI_RES_F32 stores them, the statistics of this wave's 128 columns of its 64 rows, then the same values once more in the
     // operand dtype through LDS (whole 128-byte lines): what the LayerNorm launch behind this GEMM used to read back and write
@@ -1535,7 +1556,7 @@ int launch_ws(const GemmArgs& a, int epi, hipStream_t stream) {
 
 template <typename T>
 int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false) {
-  constexpr size_t lds = 2 * (256 + 256) * 128;
+  constexpr size_t lds = 2 * (256 + 256) * 128 + 8 * 256;   // two K-tile buffers; the staged epilogues keep the tile's bias values behind the 128 KB tile image
   if (tail) {   // 128 x 512 tile: 2 x 80 KB
     constexpr size_t ldst = 2 * (128 + 512) * 128;
     switch (epi) {

@@ -392,8 +392,65 @@ static void race_screen(int rounds) {
   gemm_set_eight_phase(1);
 }
 
+// where the time of the ViT's eight-phase GEMMs goes (256 frames: M = 65792): the same launch with different epilogues and K, so that the
+// fixed cost per tile (prologue + epilogue) separates from the K loop: T = rounds x (a + b K)
+static void vit_epi_ab(int rounds) {
+  const int M = 65792, D = 1408, I = 6144;
+  std::mt19937 rng(9);
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<_Float16> h((size_t)I * 2 * D);
+  for (auto& v : h) v = (_Float16)(0.05f * d(rng));
+  _Float16 *A, *W, *C16, *X16;
+  float *bias, *X, *stats, *rstat;
+  CK(hipMalloc((void**)&A, (size_t)M * I * 2)); CK(hipMemset(A, 0, (size_t)M * I * 2));
+  CK(hipMalloc((void**)&W, h.size() * 2)); CK(hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C16, (size_t)M * I * 2)); CK(hipMalloc((void**)&X16, (size_t)M * D * 2));
+  CK(hipMalloc((void**)&X, (size_t)M * D * 4)); CK(hipMemset(X, 0, (size_t)M * D * 4));
+  CK(hipMalloc((void**)&bias, I * 4)); CK(hipMemset(bias, 0, I * 4));
+  CK(hipMalloc((void**)&stats, (size_t)M * 11 * 8)); CK(hipMalloc((void**)&rstat, (size_t)M * 8)); CK(hipMemset(rstat, 0, (size_t)M * 8));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](const char* name, int N, int K, int epi, int tile_cfg) {
+    GemmProb p{};
+    p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.tile_cfg = tile_cfg;
+    const bool f32out = epi == EPI_RES_F32 || epi == EPI_F32 || epi == EPI_RES_F32_STAT;
+    p.C = f32out ? (void*)X : (void*)C16; p.c = RowView{0, M, N};
+    p.R = X; p.r = RowView{0, M, N}; p.aux = C16;
+    if (epi == EPI_RES_F32_STAT) { p.ln_y32 = stats; p.ln_y16 = X16; p.ln_y16v = RowView{0, M, N}; }
+    if (epi == EPI_LNF_OP || epi == EPI_LNF_GELU_OP) { p.ln_gain = bias; p.ln_y32 = rstat; }
+    double best = 1e30;
+    for (int r = 0; r < rounds; ++r) {
+      if (launch_gemm(&p, 1, epi, OP_F16, 0)) { printf("%-44s refused\n", name); return; }
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) launch_gemm(&p, 1, epi, OP_F16, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, (double)ms / 5 * 1e3);
+    }
+    const double tiles = tile_cfg == 8 ? 129.0 * 11 : 257.0 * (N / 256);
+    printf("%-44s N %4d K %4d  %7.1f us  %6.1f TF/s  %5.1f us per round of 256 tiles\n", name, N, K, best, 2.0 * M * N * K / best * 1e-6, best / (tiles / 256));
+  };
+  for (int K : {1408, 2816, 6144}) {
+    run("N = dim, mixed tiles: EPI_OP (f16 store)", D, K, EPI_OP, 8);
+    run("N = dim, mixed tiles: EPI_F32", D, K, EPI_F32, 8);
+    run("N = dim, mixed tiles: EPI_RES_F32", D, K, EPI_RES_F32, 8);
+    run("N = dim, mixed tiles: EPI_RES_F32_STAT", D, K, EPI_RES_F32_STAT, 8);
+    run("N = dim, mixed tiles: EPI_RES_OP", D, K, EPI_RES_OP, 8);
+  }
+  for (int K : {1408, 2816}) {
+    run("fc1: EPI_OP", I, K, EPI_OP, 3);
+    run("fc1: EPI_GELU_OP", I, K, EPI_GELU_OP, 3);
+    run("fc1: EPI_LNF_GELU_OP", I, K, EPI_LNF_GELU_OP, 3);
+    run("qkv: EPI_OP", 4608, K, EPI_OP, 3);
+    run("qkv: EPI_LNF_OP", 4608, K, EPI_LNF_OP, 3);
+  }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "vitepi")) { vit_epi_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "race")) { race_screen(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "chain")) { chain_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "stamp")) { ring_stamp(); return 0; }
