@@ -287,11 +287,12 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
                     void* stream);
 /* algorithmic flops of one forward over `frames` frames (2 per MAC) */
 double mra_vit_flops(mra_vit* h, int32_t frames);
-/* Per-handle options.  "ln_fold" (default 1; fp32 residual stream and dim = 256 k + 128 only, otherwise ignored): the two LayerNorms of a
+/* Per-handle options.  "ln_fold" (default 1; dim = 256 k + 128 only, otherwise ignored): the two LayerNorms of a
  * block (HF modeling_instructblip.py:392-440 layer_norm1 / layer_norm2, the callee of /root/reference/models/xinstructblip.py:262-266) are folded
  * into the GEMMs around them -- LN(x) W^T + b = rstd (x (W diag(g))^T - mu colsum(W diag(g))) + (b + W beta): the residual GEMM before a
- * LayerNorm also writes the rows' operand-dtype copy and 128-column statistics, the QKV / fc1 GEMM finishes the LayerNorm in its epilogue; the
- * fp32 rows are not read back and no LayerNorm kernel runs.  0: separate LayerNorm launches (round 2's form), for A/B and parity runs. */
+ * LayerNorm also writes the rows' operand-dtype copy and 128-column statistics (with the residual stream in the operand dtype the stream is
+ * that copy and only 64-column statistics are added), the QKV / fc1 GEMM finishes the LayerNorm in its epilogue; the rows are not read back and
+ * no LayerNorm kernel runs.  0: separate LayerNorm launches (round 2's form), for A/B and parity runs. */
 int mra_vit_set_option(mra_vit* h, const char* name, int32_t value);
 
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------------------

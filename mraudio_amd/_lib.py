@@ -94,7 +94,7 @@ PROTOTYPES = {
 # GemmFamily / GemmEpi codes of mra_debug_gemm_launches (csrc/kernels.h)
 GF_V1_64, GF_V1_128, GF_WS_256, GF_P8_256, GF_WS_128x384, GF_WS_176x384, GF_K128_64x128, GF_P8_TAIL, GF_P8_MIXED, GF_K128_64x64 = 0, 1, 3, 4, 5, 6, 7, 8, 9, 10
 EPI_OP, EPI_GELU_OP, EPI_RES_F32, EPI_F32, EPI_KV, EPI_SOFTPART, EPI_RES_OP = 0, 1, 2, 3, 4, 5, 8
-EPI_RES_F32_STAT, EPI_LNF_OP, EPI_LNF_GELU_OP = 10, 11, 12     # the ViT's folded LayerNorms (csrc/kernels.h)
+EPI_RES_F32_STAT, EPI_LNF_OP, EPI_LNF_GELU_OP, EPI_RES_OP_STAT = 10, 11, 12, 13     # the ViT's folded LayerNorms (csrc/kernels.h)
 
 
 def gemm_launches(family: int, epi: int) -> int:

@@ -498,8 +498,9 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
   }
   // EPI_RES_OP: all residual chunks first (masked column blocks read block 0 of the tile), none under a branch -- a load per
   // (block, row) next to its add is one serial memory round trip each, 16 per thread on the 256 x 256 tile
-  typename Vec8<T>::type resid[EPI == EPI_RES_OP ? TN / 64 : 1][EPI == EPI_RES_OP ? RPB : 1];
-  if constexpr (EPI == EPI_RES_OP) {
+  constexpr bool RESOP = EPI == EPI_RES_OP || EPI == EPI_RES_OP_STAT;
+  typename Vec8<T>::type resid[RESOP ? TN / 64 : 1][RESOP ? RPB : 1];
+  if constexpr (RESOP) {
 #pragma unroll
     for (int hq = 0; hq < TN / 64; ++hq) {
       const int nb = n0 + hq * 64 < P.N ? n0 + hq * 64 : n0;
@@ -524,11 +525,28 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
       if (!live[u]) continue;
       const int q = tid + (hq * RPB + u) * NT;
       typename Vec8<T>::type val = *reinterpret_cast<const typename Vec8<T>::type*>(smem + (size_t)q * 16);
-      if constexpr (EPI == EPI_RES_OP) {   // + the residual in the operand dtype, whole 16-byte chunks (the reference's fp16 add)
+      if constexpr (RESOP) {   // + the residual in the operand dtype, whole 16-byte chunks (the reference's fp16 add)
 #pragma unroll
         for (int e = 0; e < 8; ++e) val[e] = from_f32<T>((float)val[e] + (float)resid[hq][u][e]);
       }
       *reinterpret_cast<typename Vec8<T>::type*>((T*)P.C + blk + rowoff[u]) = val;
+      if constexpr (EPI == EPI_RES_OP_STAT) {
+        // the 64 columns of this row and block sit in the eight lanes tid & ~7 .. + 7 (all live or all dead together): mean and squared deviations
+        // from it of the values AS STORED, two passes so that nothing cancels
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += (float)val[e];
+        sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4);
+        const float mean = sm * (1.0f / 64.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)val[e] - mean; sq = __builtin_fmaf(d, d, sq); }
+        sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+        if ((tid & 7) == 0) {
+          const int m = m0 + (tid >> 3) + u * (NT / 8);
+          reinterpret_cast<float2*>(P.ln_y32)[(long long)m * (P.N >> 6) + (nb >> 6)] = float2{mean, sq};
+        }
+      }
     }
   }
 }
@@ -859,7 +877,7 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   constexpr int WHALF = (TAIL ? 64 : 128) * ROWB, XHALF = (TAIL ? 256 : 128) * ROWB;   // half-tile sizes: W0, W1 | X0, X1
   constexpr int BUF = 2 * WHALF + 2 * XHALF;                                           // 64 KB (80 KB) per K tile
   constexpr int WP = WHALF / 8192, XP = XHALF / 8192;                                  // DMA instructions per wave and half-tile
-  constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP || EPI == EPI_LNF_OP || EPI == EPI_LNF_GELU_OP;
+  constexpr bool STAGED = EPI == EPI_OP || EPI == EPI_GELU_OP || EPI == EPI_KV || EPI == EPI_RES_OP || EPI == EPI_RES_OP_STAT || EPI == EPI_LNF_OP || EPI == EPI_LNF_GELU_OP;
   constexpr bool RESF32 = EPI == EPI_RES_F32 || EPI == EPI_RES_F32_STAT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -1561,6 +1579,7 @@ int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false)
     constexpr size_t ldst = 2 * (128 + 512) * 128;
     switch (epi) {
       case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP, true>, a, 512, ldst, stream);
+      case EPI_RES_OP_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_OP_STAT, true>, a, 512, ldst, stream);
       case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32, true>, a, 512, ldst, stream);
       case EPI_RES_F32_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_F32_STAT, true>, a, 512, ldst, stream);
       case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32, true>, a, 512, ldst, stream);
@@ -1572,6 +1591,7 @@ int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false)
     case EPI_GELU_OP: return launch_k(gemm_p8_kernel<T, EPI_GELU_OP>, a, 512, lds, stream);
     case EPI_KV: return launch_k(gemm_p8_kernel<T, EPI_KV>, a, 512, lds, stream);
     case EPI_RES_OP: return launch_k(gemm_p8_kernel<T, EPI_RES_OP>, a, 512, lds, stream);
+    case EPI_RES_OP_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_OP_STAT>, a, 512, lds, stream);
     case EPI_RES_F32: return launch_k(gemm_p8_kernel<T, EPI_RES_F32>, a, 512, lds, stream);
     case EPI_RES_F32_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_F32_STAT>, a, 512, lds, stream);
     case EPI_LNF_OP: return launch_k(gemm_p8_kernel<T, EPI_LNF_OP>, a, 512, lds, stream);
@@ -1663,6 +1683,7 @@ int launch_t(const GemmArgs& a, int cfg, int epi, hipStream_t stream) {
     switch (epi) {
       case EPI_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_OP>, a, 512, ldst, stream));   // the ViT's un-padded QKV (N = 4224)
       case EPI_RES_OP: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP>, a, 512, ldst, stream));
+      case EPI_RES_OP_STAT: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_OP_STAT>, a, 512, ldst, stream));
       case EPI_RES_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32>, a, 512, ldst, stream));
       case EPI_RES_F32_STAT: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_RES_F32_STAT>, a, 512, ldst, stream));
       case EPI_F32: return counted(GF_P8_MIXED, epi, launch_k(gemm_p8_mixed_kernel<T, EPI_F32>, a, 512, ldst, stream));
@@ -1772,17 +1793,18 @@ int launch_gemm(const GemmProb* probs, int ngroups, int epi, int op_dtype, hipSt
     if (p.batch < 0) return -1;
     if (p.a.rpi <= 0 || (epi != EPI_KV && p.c.rpi <= 0)) return -1;
     if ((epi == EPI_RES_F32 || epi == EPI_RES_F32_STAT) && (!p.R || p.r.rpi <= 0)) return -1;
-    if (epi == EPI_RES_F32_STAT || epi == EPI_LNF_OP || epi == EPI_LNF_GELU_OP) {   // eight-phase tiles only, one plain problem
+    if (epi == EPI_RES_F32_STAT || epi == EPI_RES_OP_STAT || epi == EPI_LNF_OP || epi == EPI_LNF_GELU_OP) {   // eight-phase tiles only, one plain problem
       bool even = (p.K / 64) % 2 == 0 && p.K >= 128;
-      if (!(cfg == 2 && even && g_p8 && g_variant != 1) && !(cfg == 7 && epi == EPI_RES_F32_STAT)) return -1;
+      if (!(cfg == 2 && even && g_p8 && g_variant != 1) && !(cfg == 7 && (epi == EPI_RES_F32_STAT || epi == EPI_RES_OP_STAT))) return -1;
       if (ngroups != 1 || p.batch > 1 || p.n_mask || p.n_ragged || !p.ln_y32) return -1;
+      if (epi == EPI_RES_OP_STAT && (p.N % 64 || !p.aux || (p.c.ld & 7) || (p.c.item_stride & 7))) return -1;
       if (epi == EPI_RES_F32_STAT && (p.N % 128 || !p.ln_y16 || p.ln_y16v.rpi <= 0 || (p.ln_y16v.ld & 7) || (p.ln_y16v.item_stride & 7) || (p.c.ld & 3) || (p.c.item_stride & 3))) return -1;
-      if (epi != EPI_RES_F32_STAT && (!p.ln_gain || (p.c.ld & 7) || (p.c.item_stride & 7))) return -1;
+      if ((epi == EPI_LNF_OP || epi == EPI_LNF_GELU_OP) && (!p.ln_gain || (p.c.ld & 7) || (p.c.item_stride & 7))) return -1;
     }
     if (epi == EPI_RES_LN && cfg != 10) return -1;
     if (epi == EPI_KV && (p.kv_tokens <= 0 || p.kv_heads <= 0 || p.kv_items <= 0)) return -1;
     if ((epi == EPI_OP || epi == EPI_GELU_OP || epi == EPI_RES_OP) && ((p.c.ld & 7) || (p.c.item_stride & 7))) return -1;  // 16-byte stores
-    if (epi == EPI_RES_OP && (!p.aux || p.n_ragged)) return -1;
+    if ((epi == EPI_RES_OP || epi == EPI_RES_OP_STAT) && (!p.aux || p.n_ragged)) return -1;
     if ((epi == EPI_GELU_BOTH || epi == EPI_GELU_BWD) && (!p.aux || (p.c.ld & 3) || (p.c.item_stride & 3) || p.n_ragged)) return -1;
     p.mtiles = (p.M + tm - 1) / tm;
     p.ntiles = (p.N + t - 1) / t;

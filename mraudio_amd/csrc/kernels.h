@@ -29,6 +29,8 @@ enum GemmEpi {
   EPI_RES_F32_STAT = 10,  // EPI_RES_F32, plus: ln_y16 (op dtype, row view ln_y16v) = the finished rows, and per (row, 128-column group) the
                           // group mean and the group's sum of squared deviations, ln_y32[(m * (N / 128) + n / 128) * 2 + {0, 1}]
                           // (launch_ln_group_stats folds the groups into (mean, rstd) per row).  Eight-phase tiles only (a wave owns 128 columns).
+  EPI_RES_OP_STAT = 13,   // EPI_RES_OP (residual stream in the operand dtype), plus the statistics of the ROUNDED rows per (row, 64-column block):
+                          // ln_y32[(m * (N / 64) + n / 64) * 2 + {0, 1}]; the stream itself is the consumer's operand, no copy.  Eight-phase tiles only.
   EPI_LNF_OP = 11,        // C(op dtype) = rstd[m] * (acc - mu[m] * ln_gain[n]) + bias[n]; (mu, rstd)[m] = ln_y32[2 m], ln_y32[2 m + 1]; ln_gain = colsum(W')
   EPI_LNF_GELU_OP = 12,   // gelu_erf of the same (256 x 256 eight-phase tile only, both)
   EPI_SOFTPART = 5, // C(op dtype) = exp2(alpha * acc - max over the tile's columns of the row); the row's tile maximum and tile

@@ -280,8 +280,8 @@ __global__ void __launch_bounds__(256) vit_fold_weight_kernel(const T* W, const 
   if (lane == 0) { cs[n] = c; bf[n] = b + (bias ? bias[n] : 0.f); }
 }
 
-// groups[m][g] = (mean, sum of squared deviations) of 128 columns -> stats[m] = (mean, rstd) of the row (Chan et al.: equal counts)
-__global__ void __launch_bounds__(256) vit_group_stats_kernel(const float2* groups, long long M, int G, float eps, float2* stats) {
+// groups[m][g] = (mean, sum of squared deviations) of `gsz` columns -> stats[m] = (mean, rstd) of the row (Chan et al.: equal counts)
+__global__ void __launch_bounds__(256) vit_group_stats_kernel(const float2* groups, long long M, int G, float gsz, float eps, float2* stats) {
   const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   const float2* g = groups + m * G;
@@ -289,8 +289,32 @@ __global__ void __launch_bounds__(256) vit_group_stats_kernel(const float2* grou
   for (int i = 0; i < G; ++i) mean += g[i].x;
   mean /= (float)G;
   float m2 = 0.f;
-  for (int i = 0; i < G; ++i) { const float d = g[i].x - mean; m2 += g[i].y + 128.f * d * d; }
-  stats[m] = float2{mean, 1.0f / sqrtf(m2 / (128.f * (float)G) + eps)};
+  for (int i = 0; i < G; ++i) { const float d = g[i].x - mean; m2 += g[i].y + gsz * d * d; }
+  stats[m] = float2{mean, 1.0f / sqrtf(m2 / (gsz * (float)G) + eps)};
+}
+
+// the same for a residual stream kept in the operand dtype (the stream is its own copy): statistics of the rounded rows
+template <typename T>
+__global__ void __launch_bounds__(256) vit_row_stats16_kernel(const T* x, long long M, int D, float eps, float2* stats) {
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const T* row = x + m * D;
+  const int it = D >> 7;
+  float2 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    v[t] = t < it ? float2{(float)row[(t * 64 + lane) * 2], (float)row[(t * 64 + lane) * 2 + 1]} : float2{0.f, 0.f};
+    s += v[t].x + v[t].y;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < it) { const float a = v[t].x - mean, b = v[t].y - mean; q += a * a + b * b; }
+  q = wave_sum(q);
+  if (lane == 0) stats[m] = float2{mean, 1.0f / sqrtf(q / (float)D + eps)};
 }
 
 // the rows the first block reads (patch embedding + positions): (mean, rstd) and the op-dtype copy; one wave per row, D = 128 k <= 2048
@@ -344,12 +368,12 @@ struct mra_vit {
   bool tail_tile = true;   // N = dim GEMMs: full 256-wide tiles + a 128 x 512 tail tile per pair of row tiles (false: a masked sixth 256-wide column tile)
   int proj_tile = 3;   // GemmProb::tile_cfg of the N = dim GEMMs: 256 x 256 with a masked last column tile (1408 = 5.5 tiles); the exact-fit
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
-  // LayerNorms folded into the QKV / fc1 GEMMs (fp32 residual stream, dim = 256 k + 128): mra_vit_set_option("ln_fold", 0 / 1)
+  // LayerNorms folded into the QKV / fc1 GEMMs (dim = 256 k + 128): mra_vit_set_option("ln_fold", 0 / 1)
   int ln_fold = 1;
   bool fold_ready = false;   // W diag(gain) etc. are up to date with the loaded parameters
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
-  bool can_fold() const {
-    return cfg.residual_dtype == MRA_F32 && proj_tile == 3 && tail_tile && cfg.dim % 256 == 128 && cfg.dim > 128 && cfg.dim <= 2048 && cfg.mlp % 128 == 0;
+  bool can_fold() const {   // either residual dtype
+    return proj_tile == 3 && tail_tile && cfg.dim % 256 == 128 && cfg.dim > 128 && cfg.dim <= 2048 && cfg.mlp % 128 == 0;
   }
 };
 
@@ -525,7 +549,8 @@ size_t mra_vit_workspace_bytes(mra_vit* h, int32_t frames) {
   const size_t M = (size_t)frames * h->S;
   const size_t big = vit_big_bytes(h, (size_t)frames);
   // folded LayerNorms: the op-dtype copy of the residual rows, the 128-column group statistics and (mean, rstd) per row
-  const size_t fold = h->can_fold() ? align_up(M * h->cfg.dim * 2) + align_up(M * (h->cfg.dim / 128) * 8) + align_up(M * 8) : 0;
+  // (with the stream in the operand dtype the stream is its own copy and the groups are 64 columns wide: the copy's space holds them easily)
+  const size_t fold = h->can_fold() ? align_up(M * h->cfg.dim * 2) + align_up(M * (h->cfg.dim / 64) * 8) + align_up(M * 8) : 0;
   return align_up(M * h->cfg.dim * 2) + align_up(big) + fold + 4096;
 }
 
@@ -588,15 +613,22 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
   const bool fold = h->ln_fold && h->can_fold();
   char* x16 = big + align_up(vit_big_bytes(h, (size_t)n));
   float2* groups = reinterpret_cast<float2*>(x16 + align_up((size_t)M * D * 2));
-  float2* rstat = reinterpret_cast<float2*>(reinterpret_cast<char*>(groups) + align_up((size_t)M * (D / 128) * 8));
+  float2* rstat = reinterpret_cast<float2*>(reinterpret_cast<char*>(groups) + align_up((size_t)M * (D / 64) * 8));
+  const int gsz = r16 ? 64 : 128;   // columns per statistics group: a lane octet of the staged copy-out / a wave's half of the tile
   if (fold) {
     if (!h->fold_ready && (rc = fold_weights(h, st))) return chk(rc, "vit LayerNorm fold of the weights");
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
-    if (op == OP_F16) hipLaunchKernelGGL(vit_row_stats_kernel<f16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (f16*)x16);
-    else hipLaunchKernelGGL(vit_row_stats_kernel<bf16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (bf16*)x16);
+    if (r16) {
+      x16 = (char*)x;   // the stream is the operand
+      if (op == OP_F16) hipLaunchKernelGGL(vit_row_stats16_kernel<f16>, grid, block, 0, st, (const f16*)x, M, D, c.ln_eps, rstat);
+      else hipLaunchKernelGGL(vit_row_stats16_kernel<bf16>, grid, block, 0, st, (const bf16*)x, M, D, c.ln_eps, rstat);
+    } else {
+      if (op == OP_F16) hipLaunchKernelGGL(vit_row_stats_kernel<f16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (f16*)x16);
+      else hipLaunchKernelGGL(vit_row_stats_kernel<bf16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (bf16*)x16);
+    }
   }
   auto row_stats = [&]() {
-    hipLaunchKernelGGL(vit_group_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, groups, M, D / 128, c.ln_eps, rstat);
+    hipLaunchKernelGGL(vit_group_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, groups, M, D / gsz, (float)gsz, c.ln_eps, rstat);
   };
   for (int li = 0; li < c.depth; ++li) {
     const VitLayer& L = h->layers[li];
@@ -630,8 +662,9 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       const bool split = h->proj_tile == 3 && h->tail_tile && D % 256 == 128 && D > 128 && K % 128 == 0;
       if (split) { p.tile_cfg = 8; p.n_mask = 0; p.order = 0; }
       if (stat) {   // the rows' op-dtype copy and group statistics for the folded LayerNorm behind this GEMM (can_fold() implies split)
-        p.ln_y32 = reinterpret_cast<float*>(groups); p.ln_y16 = x16; p.ln_y16v = plain((int)M, D);
-        epi = EPI_RES_F32_STAT;
+        p.ln_y32 = reinterpret_cast<float*>(groups);
+        if (r16) epi = EPI_RES_OP_STAT;
+        else { p.ln_y16 = x16; p.ln_y16v = plain((int)M, D); epi = EPI_RES_F32_STAT; }
       }
       return launch_gemm(&p, 1, epi, op, st);
     };

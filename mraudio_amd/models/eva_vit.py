@@ -137,8 +137,8 @@ class HipEvaViTg(EvaViTg):
     container (state_dict keys unchanged); ``forward`` runs ALL given frames as one batched pass of hand-written gfx950
     kernels -- the four GEMMs per block on the eight-phase MFMA kernels with bias / GELU / residual fused, a 96-padded
     attention core -- and returns ``[n, 257, 1408]``: fp32 with the default fp32 residual stream, the operand dtype with
-    ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  With the fp32 stream the
-    two LayerNorms of a block are folded into the GEMMs around them (``ln_fold``, ``mra_vit_set_option``; ``ln_fold=False`` runs them
+    ``residual="op"`` (every residual add rounds to 16 bits, as LAVIS' ``precision="fp16"`` encoder does).  The two
+    LayerNorms of a block are folded into the GEMMs around them (``ln_fold``, ``mra_vit_set_option``; ``ln_fold=False`` runs them
     as separate launches).  No CPU path."""
 
     def __init__(self, *args, op_dtype: torch.dtype = torch.float16, residual: str = "fp32", device=None, ln_fold: bool = True, **kw):

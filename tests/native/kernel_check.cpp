@@ -509,6 +509,47 @@ static void test_gemm_ln_fold(int op, int M, int D, int K1, int N2, bool gelu, f
   report(name, worst, op == OP_F16 ? 4e-3 * (1 + offset / 4) : 3e-2 * (1 + offset / 4));
 }
 
+// EPI_RES_OP_STAT: the operand-dtype residual stream updated in place exactly as EPI_RES_OP does (bit for bit), plus per (row, 64 columns)
+// the mean and the squared deviations of the values as stored
+static void test_gemm_res_op_stat(int op, int M, int N, int K, float offset) {
+  std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K), X((size_t)M * N);
+  for (auto& v : A) v = to_op(frand(), op);
+  for (auto& v : W) v = to_op(frand(0.05f), op);
+  for (auto& v : X) v = to_op(offset + frand(2.f), op);
+  std::vector<float> bias(N);
+  for (auto& v : bias) v = frand(0.5f);
+  const int G = N / 64;
+  Dev<uint16_t> dA(A), dW(W), dX0(X), dX1(X);
+  Dev<float> dB(bias), dG((size_t)M * G * 2);
+  dG.fill(0xFF);
+  int rc = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    GemmProb p;
+    memset(&p, 0, sizeof(p));
+    uint16_t* x = pass ? dX1.p : dX0.p;
+    p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = dB.p; p.C = x; p.aux = x; p.c = RowView{0, M, N};
+    p.M = M; p.N = N; p.K = K; p.tile_cfg = N % 256 ? 8 : 3; p.ln_y32 = dG.p;
+    rc = launch_gemm(&p, 1, pass ? EPI_RES_OP_STAT : EPI_RES_OP, op, 0);
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> x0 = dX0.get(), x1 = dX1.get();
+  std::vector<float> g = dG.get();
+  double worst = rc ? 1e30 : 0;
+  for (size_t i = 0; i < x0.size() && !rc; ++i) if (x0[i] != x1[i]) { worst = 1e30; break; }
+  for (int m = 0; m < M && !rc; ++m)
+    for (int b = 0; b < G; ++b) {
+      double mean = 0, q = 0;
+      for (int n = 0; n < 64; ++n) mean += from_op(x1[(size_t)m * N + b * 64 + n], op);
+      mean /= 64;
+      for (int n = 0; n < 64; ++n) { const double d = from_op(x1[(size_t)m * N + b * 64 + n], op) - mean; q += d * d; }
+      worst = std::max(worst, fabs(g[((size_t)m * G + b) * 2] - mean) / (1 + fabs(mean)));
+      worst = std::max(worst, fabs(g[((size_t)m * G + b) * 2 + 1] - q) / (1 + q));
+    }
+  char name[160];
+  snprintf(name, sizeof(name), "gemm operand-dtype residual + 64-column statistics %s M%d N%d K%d offset %.0f", op == OP_F16 ? "f16" : "bf16", M, N, K, offset);
+  report(name, worst, 1e-5);
+}
+
 // n_mask: N not a multiple of the tile, plain [M][N] output rows; columns past N are neither read (bias, residual) nor stored
 static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   std::vector<uint16_t> A((size_t)M * K), W((size_t)N * K);
@@ -1225,6 +1266,9 @@ int main(int argc, char** argv) {
   test_gemm_ln_fold(OP_F16, 1300, 1408, 128, 256, true, 0.f);      // the ViT's width: 11 groups, odd number of row tiles, GELU consumer
   test_gemm_ln_fold(OP_F16, 520, 640, 384, 256, false, 8.f);       // row means 8 sigma from zero
   test_gemm_ln_fold(OP_BF16, 600, 512, 128, 512, true, 0.f);       // N = 256 k: full tiles only (tile_cfg 3)
+  test_gemm_res_op_stat(OP_F16, 1300, 1408, 128, 0.f);             // the same for the residual stream in the operand dtype: mixed tiles, ragged M
+  test_gemm_res_op_stat(OP_F16, 520, 640, 384, 8.f);
+  test_gemm_res_op_stat(OP_BF16, 600, 512, 128, 0.f);              // full tiles only
   test_gemm(7, EPI_RES_F32, OP_F16, 1300, 384, 256, true);         // tile_cfg 8: 256-wide tiles + 128 x 512 tail tiles in one launch; odd number of row tiles
   test_gemm(7, EPI_F32, OP_BF16, 1024, 640, 128, false);
   test_gemm(7, EPI_RES_OP, OP_F16, 2100, 1408, 384, true);
