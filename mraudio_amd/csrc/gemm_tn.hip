@@ -31,12 +31,31 @@ __device__ __forceinline__ long long tn_row_off(const RowView& v, int m) {
 }
 
 template <typename T>
+__device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& a, int nb, int kb);
+
+template <typename T>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTnArgs a) {
+  gemm_tn_body<T>(a, blockIdx.x, blockIdx.y);
+}
+
+// several weight gradients in one launch: grid.x runs over the 64-row blocks of every job's dW one after the other
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_group_kernel(const GemmTnGroup g) {
+  int job = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_TN_MAX_JOBS; ++i)
+    if (i < g.njobs && (int)blockIdx.x >= g.nb_begin[i]) job = i;
+  const GemmTnArgs& a = g.j[job];
+  if ((int)blockIdx.y * 64 >= a.K) return;          // grid.y covers the widest job (workgroup-uniform)
+  gemm_tn_body<T>(a, blockIdx.x - g.nb_begin[job], blockIdx.y);
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& a, int nb, int kb) {   // nb, kb: 64-column blocks of dY and of X
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = blockIdx.x, kb = blockIdx.y;     // 64-column blocks of dY and of X
   const T* Y = (const T*)a.dY + (long long)nb * a.y_block_stride;
   const T* X = (const T*)a.X + (long long)kb * a.x_block_stride;
   const int M = a.M;
@@ -194,6 +213,38 @@ int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream) {
   const size_t lds = 6 * TILE_B;
   if (op_dtype == OP_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_gemm_tn_group(const GemmTnArgs* jobs, int njobs, int op_dtype, hipStream_t stream) {
+  if (njobs < 1 || njobs > GEMM_TN_MAX_JOBS) return -1;
+  if (njobs == 1) return launch_gemm_tn(jobs[0], op_dtype, stream);
+  GemmTnGroup g;
+  g.njobs = njobs;
+  int tiles = 0, kmax = 0, min_steps = 1 << 30, nb = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const GemmTnArgs& a = jobs[i];
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.N % 64 || a.K % 64) return -1;
+    if (a.yv.rpi <= 0 || a.xv.rpi <= 0 || (a.yv.ld & 7) || (a.xv.ld & 7)) return -1;
+    g.j[i] = a;
+    g.nb_begin[i] = nb;
+    nb += a.N / 64;
+    tiles += (a.N / 64) * (a.K / 64);
+    kmax = std::max(kmax, a.K / 64);
+    min_steps = std::min(min_steps, (a.M + BMT - 1) / BMT);
+  }
+  for (int i = njobs; i < GEMM_TN_MAX_JOBS; ++i) { g.j[i] = jobs[0]; g.nb_begin[i] = nb; }
+  g.nb_begin[GEMM_TN_MAX_JOBS] = nb;
+  // the contraction split: enough workgroups for ~4 per CU, at least four steps each; one factor for all jobs
+  int splits = (1024 + tiles - 1) / tiles;
+  splits = std::max(1, std::min(splits, min_steps / 4));
+  if (splits > 1)
+    for (int i = 0; i < njobs; ++i)
+      if (!jobs[i].accumulate) return -1;
+  const dim3 grid(nb, kmax, splits), block(256);
+  const size_t lds = 6 * TILE_B;
+  if (op_dtype == OP_F16) hipLaunchKernelGGL(gemm_tn_group_kernel<f16>, grid, block, lds, stream, g);
+  else hipLaunchKernelGGL(gemm_tn_group_kernel<bf16>, grid, block, lds, stream, g);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -169,6 +169,18 @@ struct GemmTnArgs {
                    // multiply their dY fragments by a ones operand: two more MFMAs per step instead of a second launch)
 };
 int launch_gemm_tn(const GemmTnArgs& a, int op_dtype, hipStream_t stream);
+// Up to GEMM_TN_MAX_JOBS weight gradients in ONE launch (the weight gradients that become computable at the same point of the backward:
+// query / key / value / output of a self-attention, the two matrices of a feed-forward, ...).  A weight gradient of the layer chain is ~150
+// output tiles of a few hundred contraction rows: a launch of its own is a chip full of short, latency-bound workgroups (21 us on average, 240
+// of them per training step); launched together the jobs' workgroups share the CUs.  All jobs must be accumulating (dW += ...) when the
+// contraction is split (it is split by the same factor for every job).
+constexpr int GEMM_TN_MAX_JOBS = 4;
+struct GemmTnGroup {
+  GemmTnArgs j[GEMM_TN_MAX_JOBS];
+  int njobs;
+  int nb_begin[GEMM_TN_MAX_JOBS + 1];   // filled by the launcher: first 64-row block of dW (grid.x index) of every job
+};
+int launch_gemm_tn_group(const GemmTnArgs* jobs, int njobs, int op_dtype, hipStream_t stream);
 // db[n] (+)= sum_m dY[m][n]
 int launch_colsum(const void* dY, long long block_stride, RowView yv, int M, int N, float* db, int accumulate, int op_dtype,
                   hipStream_t stream);

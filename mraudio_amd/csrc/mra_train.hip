@@ -162,13 +162,23 @@ struct Ctx {
     p.M = M; p.N = N; p.K = K;
     return launch_gemm(&p, 1, epi, op, stream);
   }
-  // dW += dY^T X, db += colsum(dY); dY given as [M, ldy] row view starting at column block `cb0`
+  // dW += dY^T X, db += colsum(dY); dY given as [M, ldy] row view starting at column block `cb0`.  Queued: the weight gradients that become
+  // computable at the same point of the backward leave together in wflush() (launch_gemm_tn_group: up to four per launch)
+  mutable std::vector<GemmTnArgs> pending;
   int wgrad(const void* dY, RowView yv, long long y_block_stride, const void* X, RowView xv, int M, int N, int K, float* dW, float* db) const {
     if (M <= 0) return 0;
     GemmTnArgs a{};
     a.dY = dY; a.X = X; a.dW = dW; a.yv = yv; a.xv = xv; a.y_block_stride = y_block_stride; a.x_block_stride = 64;
     a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1; a.db = db;
-    return launch_gemm_tn(a, op, wstream);
+    pending.push_back(a);
+    return 0;
+  }
+  int wflush() const {
+    int rc = 0;
+    for (size_t i = 0; i < pending.size() && !rc; i += GEMM_TN_MAX_JOBS)
+      rc = launch_gemm_tn_group(pending.data() + i, (int)std::min<size_t>(GEMM_TN_MAX_JOBS, pending.size() - i), op, wstream);
+    pending.clear();
+    return rc;
   }
 };
 
@@ -304,7 +314,7 @@ int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const in
     return fail(MRA_ENOMEM, "training workspace too small or misaligned");
   hipStream_t stream = as_stream(stream_);
   const int N = items, Q = c.n_query, S = Q + L, H = c.hidden, I = c.inter;
-  const Ctx X{h, stream, h->op(), stream};
+  const Ctx X{h, stream, h->op(), stream, {}};
   const int op = X.op;
   TrainBufs t = layout_train(h, (char*)workspace, N, L, kv);
   const long long SH = (long long)S * H;
@@ -381,7 +391,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
   // the data-gradient chain.  fork(): the side stream waits for everything issued on `stream` so far (the dY it is about to
   // read); done(): an event on the side stream that `stream` waits for before it overwrites a scratch tensor those GEMMs read;
   // the call ends with a join, so to the caller everything still happens on `stream`.
-  const Ctx X{h, stream, h->op(), h->wg_stream};   // measured: backward 10.7 -> 8.6 ms at B = 1 x T = 20, both modalities
+  const Ctx X{h, stream, h->op(), h->wg_stream, {}};   // measured: backward 10.7 -> 8.6 ms at B = 1 x T = 20, both modalities
   const int op = X.op;
   int evi = 0;
   auto next_event = [&]() { return h->wg_ev[evi++ % (int)(sizeof(h->wg_ev) / sizeof(h->wg_ev[0]))]; };
@@ -488,6 +498,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
         return chk(rc, "dWcq");
       if ((rc = X.gemm(t.dqc16, qc_rows, W.wcqT, nullptr, dh1, q_view, t.dpre2_32, qc_rows, N * Q, H, H, EPI_RES_F32))) return chk(rc, "d_h1q");
     }
+    if ((rc = X.wflush())) return chk(rc, "feed-forward / cross-attention weight gradients");
     ffn_done = done();   // behind this layer's feed-forward and cross-attention weight gradients
     // ---- self-attention block: h1 = LN(pre1), pre1 = ctx Wo^T + b + hin ----
     if (attn_done) wait_for(attn_done);   // dpre16b / dqkv16 are about to be rewritten
@@ -519,6 +530,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
       if ((rc = X.wgrad(t.dqkv16 + (size_t)j * H * 2, plain(N * S, 3 * H), 64, b.hin16, all_rows, N * S, H, H,
                         G(p + "attention.self." + names[j] + ".weight"), G(p + "attention.self." + names[j] + ".bias"))))
         return chk(rc, "dWqkv");
+    if ((rc = X.wflush())) return chk(rc, "self-attention weight gradients");
     attn_done = done();
     // gradient w.r.t. the layer input: d_pre1 (residual) + dqkv Wqkv  -> becomes dh of layer i-1
     if ((rc = X.gemm(t.dqkv16, plain(N * S, 3 * H), W.wqkvT, nullptr, dh, all_rows, t.dpre32, all_rows, N * S, H, 3 * H, EPI_RES_F32))) return chk(rc, "d_hin");
@@ -549,6 +561,7 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
         return chk(rc, "dWkv");
     }
   }
+  if ((rc = X.wflush())) return chk(rc, "cross K / V weight gradients");
   return MRA_OK;
   };   // body
   const int rc_body = body();

@@ -828,6 +828,53 @@ static void test_gemm_tn(int op, int M, int N, int K, bool headmajor, bool accum
 }
 
 // ------------------------------------------------------------------------------------------------
+// several weight gradients in one launch (launch_gemm_tn_group): jobs of different N / K sharing the contraction length, accumulating into
+// pre-filled dW / db; each job against the double-precision product
+static void test_gemm_tn_group(int op, int M, int njobs) {
+  const int Ns[4] = {128, 64, 192, 64}, Ks[4] = {64, 192, 128, 256};
+  std::vector<std::vector<uint16_t>> Y(njobs), X(njobs);
+  std::vector<std::vector<float>> W0(njobs), B0(njobs);
+  std::vector<Dev<uint16_t>*> dY, dX;
+  std::vector<Dev<float>*> dW, dB;
+  std::vector<GemmTnArgs> jobs(njobs);
+  for (int j = 0; j < njobs; ++j) {
+    const int N = Ns[j], K = Ks[j];
+    Y[j].resize((size_t)M * N); X[j].resize((size_t)M * K); W0[j].resize((size_t)N * K); B0[j].resize(N);
+    for (auto& v : Y[j]) v = to_op(frand(), op);
+    for (auto& v : X[j]) v = to_op(frand(), op);
+    for (auto& v : W0[j]) v = frand();
+    for (auto& v : B0[j]) v = frand();
+    dY.push_back(new Dev<uint16_t>(Y[j])); dX.push_back(new Dev<uint16_t>(X[j])); dW.push_back(new Dev<float>(W0[j])); dB.push_back(new Dev<float>(B0[j]));
+    GemmTnArgs& a = jobs[j];
+    memset(&a, 0, sizeof(a));
+    a.dY = dY[j]->p; a.X = dX[j]->p; a.dW = dW[j]->p; a.db = j == 1 ? nullptr : dB[j]->p;
+    a.yv = RowView{0, M, N}; a.xv = RowView{0, M, K}; a.y_block_stride = 64; a.x_block_stride = 64;
+    a.M = M; a.N = N; a.K = K; a.ldw = K; a.accumulate = 1;
+  }
+  const int rc = launch_gemm_tn_group(jobs.data(), njobs, op, 0);
+  CK(hipDeviceSynchronize());
+  double worst = rc ? 1e30 : 0;
+  for (int j = 0; j < njobs && !rc; ++j) {
+    const int N = Ns[j], K = Ks[j];
+    std::vector<float> w = dW[j]->get(), b = dB[j]->get();
+    for (int n = 0; n < N; ++n) {
+      double bs = B0[j][n];
+      for (int m = 0; m < M; ++m) bs += from_op(Y[j][(size_t)m * N + n], op);
+      if (j != 1) worst = std::max(worst, fabs(b[n] - bs) / (1 + fabs(bs)));
+      else if (b[n] != B0[j][n]) worst = 1e30;                       // no bias gradient asked for: untouched
+      for (int k = 0; k < K; ++k) {
+        double acc = W0[j][(size_t)n * K + k];
+        for (int m = 0; m < M; ++m) acc += (double)from_op(Y[j][(size_t)m * N + n], op) * from_op(X[j][(size_t)m * K + k], op);
+        worst = std::max(worst, fabs(w[(size_t)n * K + k] - acc) / (1 + fabs(acc)));
+      }
+    }
+  }
+  char name[128];
+  snprintf(name, sizeof(name), "gemm_tn group of %d jobs %s M%d", njobs, op == OP_F16 ? "f16" : "bf16", M);
+  report(name, worst, 2e-4);
+  for (auto p : dY) delete p; for (auto p : dX) delete p; for (auto p : dW) delete p; for (auto p : dB) delete p;
+}
+
 static void test_ln_rows(int op) {
   const int items = 5, S = 9, H = 768, rpi = 4, off = 2;
   std::vector<float> x((size_t)items * S * H), g(H), b(H);
@@ -1214,6 +1261,9 @@ int main(int argc, char** argv) {
   test_gemm_tn(OP_F16, 1040, 128, 192, false, true);
   test_gemm_tn(OP_BF16, 333, 192, 128, false, false);
   test_gemm_tn(OP_F16, 300, 128, 64, true, true);
+  test_gemm_tn_group(OP_F16, 1040, 4);
+  test_gemm_tn_group(OP_BF16, 333, 3);
+  test_gemm_tn_group(OP_F16, 100, 2);
   test_ln_bwd();
   test_gelu_transpose_embed();
   test_attn_bwd(3, 2, 45, 45, true);
