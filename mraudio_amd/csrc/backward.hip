@@ -36,10 +36,15 @@ __device__ __forceinline__ void st4(T* p, f32x4 v) {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward.  H = 256 * NV.  RPW rows per wave, 4 waves per workgroup.
 // ---------------------------------------------------------------------------------------------
+// Two independent jobs in one launch (the query-row and the text-row LayerNorm of a Q-Former layer): workgroups [0, wg_a) take `a0`, the
+// rest `a1`.  A single job: wg_a = gridDim.x.
 template <typename T, int NV>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
+__global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a0, LnBwdArgs a1, int wg_a) {
   constexpr int H = NV * 256, RPW = 4;
   __shared__ float red[2][4][H];
+  const bool second = (int)blockIdx.x >= wg_a;          // workgroup-uniform
+  const LnBwdArgs& a = second ? a1 : a0;
+  const int wg = second ? blockIdx.x - wg_a : blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 dg[NV], db[NV];
 #pragma unroll
@@ -48,7 +53,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) gam[i] = *reinterpret_cast<const f32x4*>(a.gamma + (i * 64 + lane) * 4);
   for (int rr = 0; rr < RPW; ++rr) {
-    const int row = (blockIdx.x * 4 + wave) * RPW + rr;
+    const int row = (wg * 4 + wave) * RPW + rr;
     if (row >= a.rows) break;
     const float* xr = a.x + brow(a.xv, row);
     const float* dyr = a.dy + brow(a.dyv, row);
@@ -666,11 +671,16 @@ __global__ void __launch_bounds__(256) axpy_kernel(const float* x, float* y, lon
 
 }  // namespace
 
-int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream) {
-  if (a.rows <= 0) return 0;
+int launch_ln_bwd2(const LnBwdArgs& a, const LnBwdArgs* b, int H, int op_dtype, hipStream_t stream) {
+  const int rows_b = b ? b->rows : 0;
+  if (a.rows <= 0 && rows_b <= 0) return 0;
+  if (a.rows <= 0) return launch_ln_bwd2(*b, nullptr, H, op_dtype, stream);
   if (H % 256 || H > 1024 || H <= 0) return -1;
-  const dim3 grid((a.rows + 15) / 16), block(256);
-#define MRA_LNB(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, stream, a)
+  if (b && (b->dgamma != nullptr) != (a.dgamma != nullptr)) return -1;   // the kernel's tail branches on the first job's pointer being set per job: keep them alike
+  const int wg_a = (a.rows + 15) / 16, wg_b = rows_b > 0 ? (rows_b + 15) / 16 : 0;
+  const dim3 grid(wg_a + wg_b), block(256);
+  const LnBwdArgs& bb = rows_b > 0 ? *b : a;
+#define MRA_LNB(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, stream, a, bb, wg_a)
   const int nv = H / 256;
   if (op_dtype == OP_F16) {
     if (nv == 1) MRA_LNB(f16, 1); else if (nv == 2) MRA_LNB(f16, 2); else if (nv == 3) MRA_LNB(f16, 3); else MRA_LNB(f16, 4);
@@ -680,6 +690,8 @@ int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream) {
 #undef MRA_LNB
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream) { return launch_ln_bwd2(a, nullptr, H, op_dtype, stream); }
 
 int launch_gelu(const void* u, const void* df, void* out, long long n, int backward, int op_dtype, hipStream_t stream) {
   if (n <= 0) return 0;

@@ -198,6 +198,8 @@ struct LnBwdArgs {
   float* dgamma; float* dbeta;    // optional, accumulated with float atomics
 };
 int launch_ln_bwd(const LnBwdArgs& a, int H, int op_dtype, hipStream_t stream);
+// two independent LayerNorm backward jobs in one launch (b may be null or empty): the query-row and the text-row LayerNorm of a Q-Former layer
+int launch_ln_bwd2(const LnBwdArgs& a, const LnBwdArgs* b, int H, int op_dtype, hipStream_t stream);
 // out = gelu_erf(u) (backward = 0) or out = df * gelu'(u) (backward = 1); operand dtype, n % 8 == 0
 int launch_gelu(const void* u, const void* df, void* out, long long n, int backward, int op_dtype, hipStream_t stream);
 struct AttnBwdArgs {

@@ -162,6 +162,21 @@ struct Ctx {
     p.M = M; p.N = N; p.K = K;
     return launch_gemm(&p, 1, epi, op, stream);
   }
+  static GemmProb prob(const void* A, RowView av, const void* W, const float* bias, void* C, RowView cv, const float* R, RowView rv, int M, int N,
+                       int K, void* aux = nullptr) {
+    GemmProb p{};
+    p.A = A; p.a = av; p.W = W; p.bias = bias; p.C = C; p.c = cv; p.R = R; p.r = rv; p.aux = aux;
+    p.M = M; p.N = N; p.K = K;
+    return p;
+  }
+  // two problems with the same epilogue in one launch; an empty one (M <= 0) is dropped
+  int gemm2(const GemmProb& p0, const GemmProb& p1, int epi) const {
+    GemmProb ps[2];
+    int n = 0;
+    if (p0.M > 0) ps[n++] = p0;
+    if (p1.M > 0) ps[n++] = p1;
+    return n ? launch_gemm(ps, n, epi, op, stream) : 0;
+  }
   // dW += dY^T X, db += colsum(dY); dY given as [M, ldy] row view starting at column block `cb0`.  Queued: the weight gradients that become
   // computable at the same point of the backward leave together in wflush() (launch_gemm_tn_group: up to four per launch)
   mutable std::vector<GemmTnArgs> pending;
@@ -362,13 +377,14 @@ int mra_qformer_forward_train(mra_qformer* h, const int64_t* input_ids, const in
     char* u_t = b.u16 + (size_t)N * Q * I * 2;
     char* f_t = b.f16 + (size_t)N * Q * I * 2;
     // up-projection + GELU in one epilogue: u16 keeps the pre-activation for the backward, f16 is the activation
-    if ((rc = X.gemm(fq16, fqv, W.wiq, W.biq, b.f16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_GELU_BOTH, b.u16))) return chk(rc, "ffn-q up");
-    if ((rc = X.gemm(b.h1_16 + t16, t_view, W.wit, W.bit, f_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_GELU_BOTH, u_t))) return chk(rc, "ffn-t up");
-    if ((rc = X.gemm(b.f16, plain(N * Q, I), W.woq, W.boq, b.pre3, q_view, fq32, fqv, N * Q, H, I, EPI_RES_F32))) return chk(rc, "ffn-q down");
-    if ((rc = X.gemm(f_t, plain(N * L, I), W.wot, W.bot, b.pre3 + t32, t_view, b.h1_32 + t32, t_view, N * L, H, I, EPI_RES_F32))) return chk(rc, "ffn-t down");
-    if ((rc = launch_ln_rows(b.pre3, q_view, N * Q, H, W.lnqg, W.lnqb, c.ln_eps, nxt32, q_view, nxt16, q_view, op, stream))) return chk(rc, "ffn-q ln");
-    if (L > 0 && (rc = launch_ln_rows(b.pre3 + t32, t_view, N * L, H, W.lntg, W.lntb, c.ln_eps, nxt32 + t32, t_view, nxt16 + t16, t_view, op, stream)))
-      return chk(rc, "ffn-t ln");
+    // the query and the text feed-forward as two problems of one launch each (as the inference forward does), their LayerNorms as one launch
+    if ((rc = X.gemm2(X.prob(fq16, fqv, W.wiq, W.biq, b.f16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, b.u16),
+                      X.prob(b.h1_16 + t16, t_view, W.wit, W.bit, f_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, u_t), EPI_GELU_BOTH))) return chk(rc, "ffn up");
+    if ((rc = X.gemm2(X.prob(b.f16, plain(N * Q, I), W.woq, W.boq, b.pre3, q_view, fq32, fqv, N * Q, H, I),
+                      X.prob(f_t, plain(N * L, I), W.wot, W.bot, b.pre3 + t32, t_view, b.h1_32 + t32, t_view, N * L, H, I), EPI_RES_F32))) return chk(rc, "ffn down");
+    if (L > 0) {
+      if ((rc = launch_ln_rows2(b.pre3, all_rows, N * S, H, W.lnqg, W.lnqb, W.lntg, W.lntb, S, Q, c.ln_eps, nxt32, all_rows, nxt16, all_rows, op, stream))) return chk(rc, "ffn ln");
+    } else if ((rc = launch_ln_rows(b.pre3, q_view, N * Q, H, W.lnqg, W.lnqb, c.ln_eps, nxt32, q_view, nxt16, q_view, op, stream))) return chk(rc, "ffn-q ln");
   }
   if (out_query && (rc = launch_copy_rows_f32(t.out32, q_view, out_query, qc_rows, N * Q, H, stream))) return chk(rc, "copy out_query");
   if (out_cls && (rc = launch_copy_rows_f32(t.out32 + t32, items_view(SH, 1, H), out_cls, plain(N, H), N, H, stream))) return chk(rc, "copy out_cls");
@@ -437,41 +453,37 @@ int mra_qformer_backward(mra_qformer* h, const int64_t* input_ids, const int64_t
     const char* f_t = b.f16 + (size_t)N * Q * I * 2;
     char* dff_t = t.dff16 + (size_t)N * Q * I * 2;
     if (ffn_done) wait_for(ffn_done);   // dpre16 / dff16 / dpre2_16 / dqc16 are about to be rewritten
-    // ---- feed-forward, query rows: out = LN(pre3), pre3 = f Woq^T + b + fq ----
+    // ---- feed-forwards, query and text rows together: out = LN(pre3), pre3 = f Wo^T + b + input; each step is ONE launch over both branches ----
+    const char* dpt16 = t.dpre16 + (size_t)N * Q * H * 2;
+    const float* dpt32 = t.dpre32 + (size_t)N * Q * H;
     {
-      LnBwdArgs a{};
+      LnBwdArgs a{}, at{};
       a.dy = dh; a.dyv = q_view; a.x = b.pre3; a.xv = q_view; a.gamma = W.lnqg; a.eps = c.ln_eps; a.rows = N * Q;
       a.dx = t.dpre32; a.dxv = qc_rows; a.dx16 = t.dpre16; a.dx16v = qc_rows;
       a.dgamma = G(p + "output_query.LayerNorm.weight"); a.dbeta = G(p + "output_query.LayerNorm.bias");
-      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-q ln bwd");
+      at.dy = dh + t32; at.dyv = t_view; at.x = b.pre3 + t32; at.xv = t_view; at.gamma = W.lntg; at.eps = c.ln_eps; at.rows = N * L;
+      at.dx = t.dpre32 + (size_t)N * Q * H; at.dxv = plain(N * L, H); at.dx16 = t.dpre16 + (size_t)N * Q * H * 2; at.dx16v = plain(N * L, H);
+      at.dgamma = G(p + "output.LayerNorm.weight"); at.dbeta = G(p + "output.LayerNorm.bias");
+      if ((rc = launch_ln_bwd2(a, L > 0 ? &at : nullptr, H, op, stream))) return chk(rc, "ffn ln bwd");
     }
-    // d(pre-activation) = (d_pre3 Woq) * gelu'(u): the GELU gradient is the data-gradient GEMM's epilogue
-    if ((rc = X.gemm(t.dpre16, qc_rows, W.woqT, nullptr, t.dff16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, EPI_GELU_BWD, b.u16))) return chk(rc, "dff-q");
+    // d(pre-activation) = (d_pre3 Wo) * gelu'(u): the GELU gradient is the data-gradient GEMM's epilogue
+    if ((rc = X.gemm2(X.prob(t.dpre16, qc_rows, W.woqT, nullptr, t.dff16, plain(N * Q, I), nullptr, qc_rows, N * Q, I, H, b.u16),
+                      X.prob(dpt16, plain(N * L, H), W.wotT, nullptr, dff_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, (void*)u_t), EPI_GELU_BWD))) return chk(rc, "dff");
     fork();
     if ((rc = X.wgrad(t.dpre16, qc_rows, 64, b.f16, plain(N * Q, I), N * Q, H, I, G(p + "output_query.dense.weight"), G(p + "output_query.dense.bias"))))
       return chk(rc, "dWoq");
     if ((rc = X.wgrad(t.dff16, plain(N * Q, I), 64, fq16, fqv, N * Q, I, H, G(p + "intermediate_query.dense.weight"), G(p + "intermediate_query.dense.bias"))))
       return chk(rc, "dWiq");
-    // d(fq) = d_pre3 (residual) + du Wiq  -> compact dhc32 (cross layers) or the query rows of dh1
-    float* dfq = W.cross_index >= 0 ? t.dhc32 : dh1;
-    const RowView dfqv = W.cross_index >= 0 ? qc_rows : q_view;
-    if ((rc = X.gemm(t.dff16, plain(N * Q, I), W.wiqT, nullptr, dfq, dfqv, t.dpre32, qc_rows, N * Q, H, I, EPI_RES_F32))) return chk(rc, "d_fq");
-    // ---- feed-forward, text rows ----
     if (L > 0) {
-      LnBwdArgs a{};
-      a.dy = dh + t32; a.dyv = t_view; a.x = b.pre3 + t32; a.xv = t_view; a.gamma = W.lntg; a.eps = c.ln_eps; a.rows = N * L;
-      a.dx = t.dpre32 + (size_t)N * Q * H; a.dxv = plain(N * L, H); a.dx16 = t.dpre16 + (size_t)N * Q * H * 2; a.dx16v = plain(N * L, H);
-      a.dgamma = G(p + "output.LayerNorm.weight"); a.dbeta = G(p + "output.LayerNorm.bias");
-      if ((rc = launch_ln_bwd(a, H, op, stream))) return chk(rc, "ffn-t ln bwd");
-      const char* dpt16 = t.dpre16 + (size_t)N * Q * H * 2;
-      const float* dpt32 = t.dpre32 + (size_t)N * Q * H;
-      if ((rc = X.gemm(dpt16, plain(N * L, H), W.wotT, nullptr, dff_t, plain(N * L, I), nullptr, qc_rows, N * L, I, H, EPI_GELU_BWD, (void*)u_t))) return chk(rc, "dff-t");
-      fork();
       if ((rc = X.wgrad(dpt16, plain(N * L, H), 64, f_t, plain(N * L, I), N * L, H, I, G(p + "output.dense.weight"), G(p + "output.dense.bias")))) return chk(rc, "dWot");
       if ((rc = X.wgrad(dff_t, plain(N * L, I), 64, b.h1_16 + t16, t_view, N * L, I, H, G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"))))
         return chk(rc, "dWit");
-      if ((rc = X.gemm(dff_t, plain(N * L, I), W.witT, nullptr, dh1 + t32, t_view, dpt32, plain(N * L, H), N * L, H, I, EPI_RES_F32))) return chk(rc, "d_h1t");
     }
+    // d(input) = d_pre3 (residual) + du Wi: query rows -> compact dhc32 (cross layers) or the query rows of dh1; text rows -> dh1
+    float* dfq = W.cross_index >= 0 ? t.dhc32 : dh1;
+    const RowView dfqv = W.cross_index >= 0 ? qc_rows : q_view;
+    if ((rc = X.gemm2(X.prob(t.dff16, plain(N * Q, I), W.wiqT, nullptr, dfq, dfqv, t.dpre32, qc_rows, N * Q, H, I),
+                      X.prob(dff_t, plain(N * L, I), W.witT, nullptr, dh1 + t32, t_view, dpt32, plain(N * L, H), N * L, H, I), EPI_RES_F32))) return chk(rc, "d_ffn_in");
     // ---- cross-attention block: hc = LN(pre2), pre2 = cctx Wco^T + b + h1[:, :32] ----
     if (W.cross_index >= 0) {
       LnBwdArgs a{};
