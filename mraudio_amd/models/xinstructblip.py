@@ -646,22 +646,33 @@ class XInstructBLIP(nn.Module):
         text = self.tokenizer(samples["text_input"], padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
         ids, tmask = text.input_ids.to(self._device), text.attention_mask.to(self._device)
         per_mod, bs, num = [], None, None
-        # (Running the two modalities on two streams, as inference does, was measured and buys nothing here: at B = 1 x T = 20
-        # the training step is bound by the GPU time of its ~900 small kernels, not by gaps between them: 17.4 vs 17.0 ms.)
+        # ``train_streams``: each modality's forward (and, since autograd runs a node's backward on its forward's stream, its backward)
+        # on its own stream.  Round 2 measured nothing from it (17.4 vs 17.0 ms: the step was bound by the GPU time of its ~1300 launches);
+        # measured again after the launch merges of round 3 -- see DESIGN.md section 8.
+        cur = torch.cuda.current_stream(self._device)
+        use_streams = bool(getattr(self, "train_streams", False))
         for m in self.modalities:
             if m not in samples and f"{m}_embeds" not in samples:
                 continue
             qf: QFormer = getattr(self, f"{m}_Qformer")
-            with torch.no_grad():
-                raw, idx, bs, num = self._encode(samples, m)
-                enc = qf.modality_ln(raw, item_index=idx, items=bs * num)
-            n = bs * num
-            ids_n, tm_n = (ids.repeat(num, 1), tmask.repeat(num, 1)) if self.compat_repeat else \
-                          (ids.repeat_interleave(num, 0), tmask.repeat_interleave(num, 0))
-            att = torch.cat([torch.ones(n, self.num_query_token, dtype=torch.long, device=self._device), tm_n], dim=1)
-            z, cls = qf.forward_train(ids_n, att, enc)
-            sim = nn.functional.cosine_similarity(z, cls[:, None, :], dim=-1, eps=1e-8)
-            per_mod.append(sim.max(dim=1).values)
+            side = self._side_stream(m) if use_streams else cur
+            if use_streams:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                with torch.no_grad():
+                    raw, idx, bs, num = self._encode(samples, m)
+                    enc = qf.modality_ln(raw, item_index=idx, items=bs * num)
+                n = bs * num
+                ids_n, tm_n = (ids.repeat(num, 1), tmask.repeat(num, 1)) if self.compat_repeat else \
+                              (ids.repeat_interleave(num, 0), tmask.repeat_interleave(num, 0))
+                att = torch.cat([torch.ones(n, self.num_query_token, dtype=torch.long, device=self._device), tm_n], dim=1)
+                z, cls = qf.forward_train(ids_n, att, enc)
+                sim = nn.functional.cosine_similarity(z, cls[:, None, :], dim=-1, eps=1e-8)
+                per_mod.append(sim.max(dim=1).values)
+        if use_streams:
+            for m in self.modalities:
+                if (m, False) in self._streams:
+                    cur.wait_stream(self._streams[(m, False)])
         w = self.fuse_weights or [1.0 / len(per_mod)] * len(per_mod)
         fused = sum(x * wt for x, wt in zip(per_mod, w))
         return {"loss": nn.functional.binary_cross_entropy_with_logits(fused.view(bs, num) * 20.0, self._targets(samples, bs, num))}

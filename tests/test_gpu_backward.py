@@ -171,6 +171,34 @@ def test_model_level_finetune_step(dev):
     assert len(out) == 1 and out[0].startswith("[[")
 
 
+def test_modalities_on_their_own_streams_give_the_same_loss_and_gradients(dev):
+    """``model.train_streams``: each modality's forward (and therefore its backward) on its own stream -- an A/B switch of
+    ``tools/bench_finetune.py --streams`` (no gain measured: DESIGN.md section 8).  Same loss, same gradients up to the summation
+    order of the weight-gradient atomics."""
+    from mraudio_amd.models.xinstructblip import XInstructBLIP
+
+    model = XInstructBLIP(seed=3, perturb=True, device=dev)
+    model.enable_qformer_training()
+    g = torch.Generator().manual_seed(5)
+    samples = {"video_embeds": torch.randn(1, 6, 257, 1408, generator=g), "audio_embeds": torch.randn(1, 6, 256, 768, generator=g),
+               "text_input": ["Query: a person opens the door.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
+               "text_output": ["[[2, 6]]"], "timestamps": [list(range(0, 12, 2))], "duration": [12]}
+    got = {}
+    for streams in (False, True):
+        model.train_streams = streams
+        for m in ("video", "audio"):
+            getattr(model, f"{m}_Qformer")._grad_flat.zero_()
+        loss = model(samples)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        got[streams] = (loss.item(), {m: getattr(model, f"{m}_Qformer")._grad_flat.clone() for m in ("video", "audio")})
+    assert abs(got[True][0] - got[False][0]) <= 1e-6 * max(1.0, abs(got[False][0]))
+    for m in ("video", "audio"):
+        a, b = got[False][1][m], got[True][1][m]
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        assert ((a - b).norm() / a.norm()).item() < 1e-4, m
+
+
 def test_flat_parameter_update_equals_per_tensor_update(dev):
     """Optimizer steps on the flat parameter (master buffer + gradient buffer) must move every per-tensor view as
     per-tensor steps would; zero_grad on the flat parameter restarts the accumulation.  Momentum SGD, not Adam:
