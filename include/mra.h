@@ -177,7 +177,8 @@ int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode);
 /* Per-handle tuning options (no reference counterpart; results are the same to fp32 summation order).
  *   "chain_ring"  mask: which GEMMs of the 12-layer chain run on the ring kernel's exact-fit tiles when the launch has ~1 k rows or more:
  *                 bit 0 QKV (144 x 128), bit 1 FFN-up (192 x 128), bit 2 the residual projections (96 x 64), bit 3 (with bit 2) their LayerNorm inside the same
- *                 launch (the last-arriving column tile of a 64-row block normalises it).  DESIGN.md section 8. */
+ *                 launch (the last-arriving column tile of a 64-row block normalises it).  DESIGN.md section 8.
+ *   "train_ring"  the same mask (bits 0 and 2) for the GEMMs of mra_qformer_forward_train / mra_qformer_backward; default 4. */
 int mra_qformer_set_option(mra_qformer* h, const char* name, int32_t value);
 /* Derives what the folded path needs from the loaded weights (W_k of every cross layer regrouped per head) on
  * `stream`, if a load made it stale.  mra_qformer_forward does this itself; a caller that runs SEVERAL forwards of one

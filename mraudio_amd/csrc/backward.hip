@@ -52,17 +52,31 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs a0, LnBwdArgs a1,
   f32x4 gam[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) gam[i] = *reinterpret_cast<const f32x4*>(a.gamma + (i * 64 + lane) * 4);
+  // all RPW rows of this wave are fetched up front (rows past the end re-read the last row and are skipped below): one memory round trip
+  // per wave instead of one per row -- a launch over ~1 k rows is a single round of latency-bound workgroups
+  const int row0 = (wg * 4 + wave) * RPW;
+  f32x4 xs[RPW][NV], dys[RPW][NV];
+#pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
-    const int row = (wg * 4 + wave) * RPW + rr;
-    if (row >= a.rows) break;
+    const int row = min(row0 + rr, a.rows - 1);
     const float* xr = a.x + brow(a.xv, row);
     const float* dyr = a.dy + brow(a.dyv, row);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xs[rr][i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+      dys[rr][i] = *reinterpret_cast<const f32x4*>(dyr + (i * 64 + lane) * 4);
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr;
+    if (row >= a.rows) break;
     f32x4 x[NV], dy[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      x[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
-      dy[i] = *reinterpret_cast<const f32x4*>(dyr + (i * 64 + lane) * 4);
+      x[i] = xs[rr][i];
+      dy[i] = dys[rr][i];
       s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
     }
     const float mean = wave_sum(s) * (1.0f / H);

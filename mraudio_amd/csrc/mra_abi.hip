@@ -1161,6 +1161,11 @@ int mra_qformer_set_cross_precision(mra_qformer* h, int32_t mode) {
 int mra_qformer_set_option(mra_qformer* h, const char* name, int32_t value) {
   if (!h || !name) return fail(MRA_EINVAL, "null argument");
   const std::string key(name);
+  if (key == "train_ring") {
+    if (value < 0 || value > 7) return fail(MRA_EINVAL, "train_ring is a mask of bits 0-2");
+    h->train_ring = value;
+    return MRA_OK;
+  }
   if (key == "chain_ring") {
     if (value < 0 || value > 15) return fail(MRA_EINVAL, "chain_ring is a mask of bits 0-3");
     h->chain_ring = value;

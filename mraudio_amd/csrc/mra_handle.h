@@ -107,6 +107,9 @@ struct mra_qformer {
   // SLOWER in the step -- 6.95 vs 6.73-6.93 ms, reference item shape 2.86-2.92 vs 2.65-2.83 -- opt-in); chosen per launch only where the tile
   // divides N and the launch has >= ~1 k rows
   int chain_ring = 7;    // measured in the step (r03d, same box): mask 0 / 1 / 3 / 7 = 6.65 / 6.64 / 6.59 / 6.56 ms; reference item shape 2.55 / 2.62 / - / 2.52 ms
+  int train_ring = 4;   // the same mask for the training forward / backward GEMMs (mra_qformer_set_option "train_ring"): bit 0 QKV, bit 2 every N = hidden
+                        // GEMM whose epilogue the ring kernel has (projections with a residual, the data gradients).  Measured at B = 1 x T = 20 (r03x,
+                        // one session): 14.6-15.2 ms per step with 0, 14.0-14.3 with 4, 14.2 with 5
   int cross_precise = 0;
   float* wk32 = nullptr;
   char* arena_p = nullptr;

@@ -159,8 +159,15 @@ struct Ctx {
     if (M <= 0) return 0;
     GemmProb p{};
     p.A = A; p.a = av; p.W = W; p.bias = bias; p.C = C; p.c = cv; p.R = R; p.r = rv; p.aux = aux;
-    p.M = M; p.N = N; p.K = K;
+    p.M = M; p.N = N; p.K = K; p.tile_cfg = ring_tile(N, epi);
     return launch_gemm(&p, 1, epi, op, stream);
+  }
+  // mra_qformer_set_option("train_ring"): the ring kernel's exact-fit tiles where it has the epilogue (GemmProb::tile_cfg, 0 = automatic)
+  int ring_tile(int N, int epi) const {
+    const int mask = h->train_ring;
+    if ((mask & 1) && epi == EPI_OP && N == 3 * h->cfg.hidden && N % 144 == 0) return 9;
+    if ((mask & 4) && (epi == EPI_OP || epi == EPI_RES_F32) && N == h->cfg.hidden && N % 96 == 0) return 11;
+    return 0;
   }
   static GemmProb prob(const void* A, RowView av, const void* W, const float* bias, void* C, RowView cv, const float* R, RowView rv, int M, int N,
                        int K, void* aux = nullptr) {
@@ -175,6 +182,7 @@ struct Ctx {
     int n = 0;
     if (p0.M > 0) ps[n++] = p0;
     if (p1.M > 0) ps[n++] = p1;
+    if (n) ps[0].tile_cfg = ring_tile(ps[0].N, epi);   // the first problem decides
     return n ? launch_gemm(ps, n, epi, op, stream) : 0;
   }
   // dW += dY^T X, db += colsum(dY); dY given as [M, ldy] row view starting at column block `cb0`.  Queued: the weight gradients that become

@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--fused-adam", action="store_true", help="A/B: the one-pass mra_qformer_adam_step (update + device-copy refresh + transposed copies + gradient "
                                                               "clearing) instead of torch.optim.Adam(fused=True) on the flat parameters; measured r03f: 17.6 vs 17.3 ms per step")
     ap.add_argument("--streams", action="store_true", help="A/B: each modality's Q-Former forward + backward on its own stream (model.train_streams)")
+    ap.add_argument("--train-ring", type=int, default=None, help="A/B: mra_qformer_set_option('train_ring', mask) on both Q-Formers")
     args = ap.parse_args(argv)
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -38,6 +39,9 @@ def main(argv=None):
     model = XInstructBLIP(seed=0, perturb=False, op_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16, device=dev)
     model.enable_qformer_training()
     model.train_streams = args.streams
+    if args.train_ring is not None:
+        for m in model.modalities:
+            getattr(model, f"{m}_Qformer").set_option("train_ring", args.train_ring)
     g = torch.Generator().manual_seed(100 + rank)
     samples = {"video_embeds": torch.randn(1, 20, 257, 1408, generator=g).to(dev), "audio_embeds": torch.randn(1, 20, 256, 768, generator=g).to(dev),
                "text_input": ["Query: a person opens the door and walks in.\nGiven the video and the query, find the relevant windows.\nRelevant windows: "],
