@@ -16,10 +16,11 @@ ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--backend", default="hip")
 ap.add_argument("--residual", default="fp32", choices=["fp32", "op"])
+ap.add_argument("--ln-fold", type=int, default=1, help="0: the blocks' LayerNorms as separate launches (mra_vit_set_option ln_fold 0)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 if a.backend == "hip":
-    vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev, residual=a.residual).eval().init_seeded_(0)
+    vit = create_eva_vit_g(224, 0, False, "fp16", backend="hip", device=dev, residual=a.residual, ln_fold=bool(a.ln_fold)).eval().init_seeded_(0)
 else:
     with torch.device(dev):
         vit = create_eva_vit_g(224, 0, False, "fp16").eval()
@@ -33,4 +34,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / a.reps
 fl = vit.flops_per_frame() * a.frames
-print(json.dumps({"backend": a.backend, "residual": a.residual if a.backend == "hip" else "f16 (torch autocast-free half model)", "frames": a.frames, "ms": round(t * 1e3, 2), "tflops": round(fl / t / 1e12, 1), "frames_per_s": round(a.frames / t, 1)}))
+print(json.dumps({"backend": a.backend, "residual": a.residual if a.backend == "hip" else "f16 (torch autocast-free half model)", "ln_fold": bool(a.ln_fold) if a.backend == "hip" else None, "frames": a.frames, "ms": round(t * 1e3, 2), "tflops": round(fl / t / 1e12, 1), "frames_per_s": round(a.frames / t, 1)}))
