@@ -202,6 +202,200 @@ __global__ void __launch_bounds__(ATT_WAVES * 64) vit_attn_kernel(const T* qkv, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same core as a PERSISTENT kernel (S = 257): one workgroup of eight waves per CU walks over (frame, head) units; while the waves work
+// on unit u out of LDS, the K / V rows of unit u + gridDim.x are already on their way into registers (56 per lane) and go to LDS behind a
+// barrier when u is done.  With one workgroup per CU (the head's K and V fill 120 KB of LDS) the stand-alone kernel above cannot hide that fetch:
+// 99 KB per unit at the ~21 GB/s one CU gets from HBM is several microseconds of a ~17 us unit.  The Q fragments of a wave's (up to three)
+// query blocks are requested BEFORE the prefetch: vmcnt retires in order, and a Q load issued behind it would wait for all of it.
+// Bit-identical to the kernel above -- and measured slower (303 vs 277 us per launch): 249 registers per lane allow eight waves, and 17 query
+// blocks over eight waves leave one wave with three blocks in series where nine waves have at most two.  Opt-in (mra_vit_set_option "attn_persist").
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ATTP_WAVES = 8;
+template <typename T, int SC>
+__global__ void __launch_bounds__(ATTP_WAVES * 64) vit_attn_persist_kernel(const T* qkv, T* ctx, int units, int heads, int hd, float sl2) {
+  static_assert(SC > 0, "compile-time sequence length");
+  constexpr int S = SC;
+  const bool ones = hd < HD_PAD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + KS_PAD * KV_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = 3 * heads * HD_PAD;
+  using V8 = typename Vec8<T>::type;
+  constexpr int NT = ATTP_WAVES * 64;
+  constexpr int NCH = (KS_PAD * 12 + NT - 1) / NT;
+  constexpr int NBLK = (SC + 15) / 16, BPW = (NBLK + ATTP_WAVES - 1) / ATTP_WAVES;   // query blocks; per wave at most
+  auto unit_base = [&](int u) {
+    const int frame = u / heads, head = u - frame * heads;
+    return qkv + (long long)frame * S * ld + head * HD_PAD;
+  };
+  V8 kr[NCH], vr[NCH];
+  auto fetch = [&](const T* base) {     // every load issued back to back, none under a lane-dependent branch (a clamped row is loaded and zeroed later)
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int c = min(tid + u * NT, KS_PAD * 12 - 1);
+      const int row = c / 12, ch = c - row * 12;
+      const T* p = base + (long long)min(row, S - 1) * ld + ch * 8;
+      kr[u] = *reinterpret_cast<const V8*>(p + heads * HD_PAD);
+      vr[u] = *reinterpret_cast<const V8*>(p + 2 * heads * HD_PAD);
+    }
+  };
+  auto to_lds = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int c = tid + u * NT;
+      const int row = c / 12, ch = c - row * 12;
+      if (row >= S) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[u][e] = from_f32<T>(0.f); vr[u][e] = kr[u][e]; }
+      }
+      if (ones && ch == (hd >> 3)) {   // the ones column (masked keys carry P = 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e == (hd & 7)) vr[u][e] = from_f32<T>(1.f);
+      }
+      if (c < KS_PAD * 12) {
+        *reinterpret_cast<V8*>(Ks + row * KV_PITCH + ch * 16) = kr[u];
+        *reinterpret_cast<V8*>(Vs + row * KV_PITCH + ch * 16) = vr[u];
+      }
+    }
+  };
+  const int lm = lane & 15, lc = lane >> 4;
+  int u = blockIdx.x;
+  if (u >= units) return;
+  fetch(unit_base(u));
+  to_lds();
+  __syncthreads();
+  for (; u < units; u += gridDim.x) {
+    const T* base = unit_base(u);
+    const int frame = u / heads, head = u - frame * heads;
+    const int un = u + gridDim.x;
+    // Q fragments (B operand) of this wave's blocks: lane (query lm, chunk lc) holds Q[q0 + lm][32 ks + 8 lc .. + 7]
+    // (assembly loads: the compiler would sink ordinary loads to their first use -- behind the prefetch -- and close them with vmcnt(0))
+    V8 qfs[BPW][3];
+    static_assert(BPW == 3, "the counted wait below names nine registers");
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      const int q0 = min(wave + b * ATTP_WAVES, NBLK - 1) * 16;
+      const T* qp = base + (long long)min(q0 + lm, S - 1) * ld + 8 * lc;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qfs[b][ks]) : "v"(qp + 32 * ks) : "memory");
+    }
+    // Unconditional (the last unit of a workgroup fetches itself again and drops it): under a branch the compiler must assume the loads may not
+    // have been issued and counts the Q fragments' vmcnt without them -- i.e. waits for most of the prefetch before the first MFMA.
+    fetch(unit_base(min(un, units - 1)));
+    // the Q fragments have landed once at most the 2 NCH prefetch loads behind them are outstanding
+    asm volatile("s_waitcnt vmcnt(%9)"
+                 : "+v"(qfs[0][0]), "+v"(qfs[0][1]), "+v"(qfs[0][2]), "+v"(qfs[1][0]), "+v"(qfs[1][1]), "+v"(qfs[1][2]), "+v"(qfs[2][0]), "+v"(qfs[2][1]), "+v"(qfs[2][2])
+                 : "n"(2 * NCH)
+                 : "memory");
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      const int qb = wave + b * ATTP_WAVES;
+      if (qb >= NBLK) break;                        // wave-uniform
+      const int q0 = qb * 16;
+      V8 qf[3] = {qfs[b][0], qfs[b][1], qfs[b][2]};
+    constexpr int NFR = SC ? (SC + 15) / 16 : KS_PAD / 16;   // key fragments with at least one valid key (compile-time S)
+    f32x4 sc[KS_PAD / 16];
+    float mx = -3.0e38f;     // of the raw scores: sl2 > 0
+#pragma unroll
+    for (int i = 0; i < KS_PAD / 16; ++i) {
+      if (i >= NFR) { sc[i] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; continue; }
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(Ks + (16 * i + lm) * KV_PITCH + (4 * ks + lc) * 16);
+        a = mfma16<T>(kf, qf[ks], a);
+      }
+      if (SC && 16 * i + 16 <= SC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, a[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (16 * i + 4 * lc + e >= S) a[e] = -3.0e38f;
+          mx = fmaxf(mx, a[e]);
+        }
+      }
+      sc[i] = a;
+    }
+    // Scheduling of the K-fragment reads against the MFMAs: six reads run ahead, then one read per MFMA.  Left alone
+    // the scheduler hoists every read above the first MFMA and the allocator spills (644 bytes of scratch per lane, 0.96 ms per
+    // layer); strictly one read per MFMA exposes the LDS latency on every MFMA (0.37 ms).
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 3 * NFR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * sl2;
+    float l = 0.f;
+    // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]
+    f32x4 ot[HD_PAD / 16];
+#pragma unroll
+    for (int df = 0; df < HD_PAD / 16; ++df) ot[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS_PAD / 32; ++ks) {
+      V8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * ks][e], sl2, -mxs)));          // masked keys: exp2(-huge) = 0
+        pf[4 + e] = 2 * ks + 1 < NFR ? from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * ks + 1][e], sl2, -mxs))) : from_f32<T>(0.f);
+        if (!ones) l += (float)pf[e] + (float)pf[4 + e];
+      }
+      // V^T fragment of d block df in the same key order: transposed 4 x 16 blocks at keys 32 ks + 4 lc and 32 ks + 16 + 4 lc
+      const char* vb = Vs + (32 * ks + 4 * lc + (lm >> 2)) * KV_PITCH + (lane & 3) * 8;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df) {
+        const i16x4 c0 = lds_read_tr4(vb + df * 32), c1 = lds_read_tr4(vb + df * 32 + 16 * KV_PITCH);
+        i16x8 v;
+        v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3]; v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+        ot[df] = mfma16<T>(__builtin_bit_cast(V8, v), pf, ot[df]);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // same for the 108 transposed V reads: four fragments ahead
+#pragma unroll
+    for (int i = 0; i < (HD_PAD / 16) * (KS_PAD / 32); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    if (ones) {
+      // O^T[hd][query]: fragment hd / 16, row hd % 16 = 4 c + e
+      float lo = 0.f;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (df == (hd >> 4) && e == (hd & 3)) lo = ot[df][e];
+      l = __shfl(lo, ((hd & 15) >> 2) * 16 + lm);
+    } else {
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+    }
+    const float inv = 1.0f / l;
+    if (q0 + lm < S) {
+      T* crow = ctx + ((long long)frame * S + q0 + lm) * (heads * hd) + head * hd;
+#pragma unroll
+      for (int df = 0; df < HD_PAD / 16; ++df) {
+        const int d = 16 * df + 4 * lc;
+        if (d + 3 < hd) {
+          typename Vec4<T>::type o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(ot[df][e] * inv);
+          *reinterpret_cast<typename Vec4<T>::type*>(crow + d) = o;
+        }
+      }
+    }
+    }
+    __syncthreads();                                // every wave is done with the K / V of unit u
+    if (un < units) to_lds();
+    __syncthreads();
+  }
+}
+
 // frames [n][3][img][img] (f32 or f16) -> patches [n * np * np][kpad] in the operand dtype, k = (c * ps + i) * ps + j, zeros past 3 ps^2
 template <typename TI, typename T>
 __global__ void __launch_bounds__(256) vit_im2col_kernel(const TI* x, T* out, long long total, int img, int ps, int np, int kpad) {
@@ -370,6 +564,10 @@ struct mra_vit {
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
   // LayerNorms folded into the QKV / fc1 GEMMs (dim = 256 k + 128): mra_vit_set_option("ln_fold", 0 / 1)
   int ln_fold = 1;
+  int attn_persist = 0;   // S = 257: the attention core as one persistent workgroup per CU that prefetches the next (frame, head) unit (vit_attn_persist_kernel).
+                          // Measured SLOWER (r03z: 303 vs 277 us per launch at 256 frames, 576-579 vs 573-576 ms per 1024 frames): its register budget allows
+                          // eight waves, and 17 query blocks over eight waves put three blocks in series on one wave; opt-in
+  int cus = 0;
   bool fold_ready = false;   // W diag(gain) etc. are up to date with the loaded parameters
   int op() const { return cfg.op_dtype == MRA_BF16 ? OP_BF16 : OP_F16; }
   bool can_fold() const {   // either residual dtype
@@ -446,6 +644,7 @@ int mra_vit_create(const mra_vit_cfg* cfg, mra_vit** out) {
   h->kpad = (3 * c.patch * c.patch + 63) / 64 * 64;
   h->nqkv = 3 * c.heads * HD_PAD;
   HIP_TRY(hipGetDevice(&h->device));
+  HIP_TRY(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device));
   h->arena_bytes = vit_layout(h, nullptr);
   const hipError_t e = hipMalloc((void**)&h->arena, h->arena_bytes);
   if (e != hipSuccess) { delete h; return fail(MRA_ENOMEM, std::string("hipMalloc of the ViT parameter arena: ") + hipGetErrorString(e)); }
@@ -522,6 +721,11 @@ int mra_vit_set_option(mra_vit* h, const char* name, int32_t value) {
   if (key == "ln_fold") {
     if (value != 0 && value != 1) return fail(MRA_EINVAL, "ln_fold: 0 or 1");
     h->ln_fold = value;
+    return MRA_OK;
+  }
+  if (key == "attn_persist") {
+    if (value != 0 && value != 1) return fail(MRA_EINVAL, "attn_persist: 0 or 1");
+    h->attn_persist = value;
     return MRA_OK;
   }
   return fail(MRA_ENAME, "unknown option: " + key);
@@ -603,7 +807,9 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
     if (hipFuncSetAttribute((const void*)vit_attn_kernel<f16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)vit_attn_kernel<bf16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)vit_attn_kernel<f16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess)
+        hipFuncSetAttribute((const void*)vit_attn_kernel<bf16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_persist_kernel<f16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vit_attn_persist_kernel<bf16, 257>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds) != hipSuccess)
       return fail(MRA_EHIP, "hipFuncSetAttribute(vit_attn_kernel)");
     attr_done |= 1ull << (h->device & 63);
   }
@@ -644,7 +850,11 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       rc = launch_gemm(&p, 1, fold ? EPI_LNF_OP : EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
-    if (S == 257) {   // ViT-g/224: the sequence length as a compile-time constant
+    if (S == 257 && h->attn_persist && h->cus > 0) {   // one persistent workgroup per CU, the next unit's K / V prefetched
+      const int units = n * c.heads, grid = std::min(units, h->cus);
+      if (op == OP_F16) hipLaunchKernelGGL((vit_attn_persist_kernel<f16, 257>), dim3(grid), dim3(ATTP_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, units, c.heads, hd, sl2);
+      else hipLaunchKernelGGL((vit_attn_persist_kernel<bf16, 257>), dim3(grid), dim3(ATTP_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, units, c.heads, hd, sl2);
+    } else if (S == 257) {   // ViT-g/224: the sequence length as a compile-time constant
       if (op == OP_F16) hipLaunchKernelGGL((vit_attn_kernel<f16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const f16*)big, (f16*)a16, S, c.heads, hd, sl2);
       else hipLaunchKernelGGL((vit_attn_kernel<bf16, 257>), dim3(n * c.heads), dim3(ATT_WAVES * 64), attn_lds, st, (const bf16*)big, (bf16*)a16, S, c.heads, hd, sl2);
     } else {

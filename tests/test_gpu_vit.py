@@ -52,6 +52,15 @@ def test_hip_vit_matches_the_hf_vectors_and_the_fp32_restatement(pair, golden_di
     more = torch.cat([make_frames(3, seed=21), frames])
     ym = hip(more.to(dev)).cpu()
     assert (ym[3:] - y).abs().max().item() < 1e-4
+    # the attention core as persistent workgroups that prefetch the next (frame, head) unit (opt-in: measured slower) against one workgroup
+    # per unit -- the same arithmetic in the same order, bit for bit
+    hip.set_option("attn_persist", 1)
+    try:
+        ya = hip(frames.to(dev)).cpu()
+        yma = hip(more.to(dev)).cpu()
+    finally:
+        hip.set_option("attn_persist", 0)
+    assert torch.equal(ya, y) and torch.equal(yma, ym)
     # the default folds the LayerNorms into the GEMMs around them; with separate LayerNorm launches (round 2's form) the same bars hold, and
     # the two forms differ from each other by less than either differs from the fp32 restatement
     hip.set_option("ln_fold", 0)

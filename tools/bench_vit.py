@@ -16,6 +16,7 @@ ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--backend", default="hip")
 ap.add_argument("--residual", default="fp32", choices=["fp32", "op"])
+ap.add_argument("--attn-persist", type=int, default=0, help="1: the attention core as persistent workgroups that prefetch the next unit (mra_vit_set_option attn_persist 1; measured slower)")
 ap.add_argument("--ln-fold", type=int, default=1, help="0: the blocks' LayerNorms as separate launches (mra_vit_set_option ln_fold 0)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -24,6 +25,8 @@ if a.backend == "hip":
 else:
     with torch.device(dev):
         vit = create_eva_vit_g(224, 0, False, "fp16").eval()
+if a.backend == "hip" and a.attn_persist:
+    vit.set_option("attn_persist", 1)
 x = torch.randn(a.frames, 3, 224, 224, device=dev, dtype=torch.float16)
 with torch.no_grad():
     vit(x)
