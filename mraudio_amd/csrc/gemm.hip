@@ -159,7 +159,8 @@ __device__ __forceinline__ void epilogue(const GemmProb& P, f32x4 (&acc)[FN][FM]
       const bool live = rok[j] && cok[i];
       f32x4 v = acc[i][j] + bv[i];
       if constexpr (EPI == EPI_GELU_OP) {
-        v = gelu_erf4(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
       if constexpr (EPI == EPI_GELU_BOTH) {     // keep the pre-activation for the backward, return the activation
         typename Vec4<T>::type u;
@@ -221,7 +222,8 @@ __device__ __forceinline__ void epilogue_lean(const GemmProb& P, f32x4 (&acc)[FN
       f32x4 v = acc[i][j];
       if (!PRE && P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n);
       if constexpr (EPI == EPI_GELU_OP) {
-        v = gelu_erf4(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
       if constexpr (EPI == EPI_GELU_BOTH) {     // keep the pre-activation for the backward, return the activation
         typename Vec4<T>::type u;
@@ -461,7 +463,8 @@ __device__ __forceinline__ void epilogue_lds16(const GemmProb& P, f32x4 (&acc)[F
         v = acc[i][j] + bv;
       }
       if constexpr (EPI == EPI_GELU_OP || EPI == EPI_LNF_GELU_OP) {
-        v = gelu_erf4(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
       typename Vec4<T>::type o;
 #pragma unroll
@@ -1302,7 +1305,8 @@ __global__ void __launch_bounds__(2 * WGN* WGM * 64) gemm_ring_kernel(const Gemm
         if (((i * FM + j) & 1) != group) continue;
         f32x4 v = acc[i][j] + in_red[((i * FM + j) >> 1) * 64] + bv;
         if constexpr (EPI == EPI_GELU_OP) {
-          v = gelu_erf4(v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
         char* dst = tile + (wm0 + j * 16 + lm) * PITCH + nl * OSZ;
         if constexpr (F32OUT) {

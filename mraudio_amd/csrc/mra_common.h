@@ -107,30 +107,4 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
 // exact (erf) GELU, as BERT's "gelu" (HF ACT2FN["gelu"], reference path uses hidden_act = "gelu")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
-// The same for the GEMM epilogues, four values at a time on pairs of floats: every multiply / fma below is a packed fp32 instruction
-// (v_pk_fma_f32, v_pk_mul_f32: two values per lane per issue), and erf comes from Abramowitz & Stegun 7.1.28,
-//   erf(a) = 1 - (1 + a1 a + ... + a6 a^6)^-16,  |error| <= 3e-7 for a >= 0,
-// which needs ONE transcendental (the reciprocal; 7.1.26 above takes a reciprocal and an exponential, each a quarter-rate instruction).
-// The fc1 + GELU epilogue of the ViT is VALU-bound: 128 values per lane after the K loop, with nothing to overlap them (one workgroup per CU).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  f32x2 a = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
-  a = __builtin_elementwise_min(a, f32x2{6.0f, 6.0f});            // erf(6) = 1 to 2e-17; keeps the sixteenth power finite
-  f32x2 p = a * 0.0000430638f + 0.0002765672f;
-  p = p * a + 0.0001520143f;
-  p = p * a + 0.0092705272f;
-  p = p * a + 0.0422820123f;
-  p = p * a + 0.0705230784f;
-  p = p * a + 1.0f;
-  p = p * p; p = p * p; p = p * p; p = p * p;
-  const f32x2 e = 1.0f - f32x2{__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-  const f32x2 erfv = f32x2{copysignf(e[0], x[0]), copysignf(e[1], x[1])};
-  const f32x2 hx = x * 0.5f;
-  return hx * erfv + hx;
-}
-__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
-  const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
 }  // namespace mra
