@@ -95,6 +95,26 @@ def test_hip_vit_with_the_reference_precision_residual(pair, dev):
     assert torch.isfinite(y0).all() and (y0 - want).abs().max().item() < 4e-2 and ((y0 - want).norm() / want.norm()).item() < 4e-3
 
 
+@pytest.mark.parametrize("residual", ["fp32", "op"])
+def test_hip_vit_bf16_operands_folded_and_separate_layernorms(dev, residual):
+    """bf16 MFMA operands (8 mantissa bits: the bars scale with 2^-8 / 2^-11 against the f16 tests): the folded-LayerNorm GEMM epilogues and the
+    separate LayerNorm launches against the fp32 restatement and against each other, both residual streams."""
+    ref = EvaViTg(depth=2).eval().init_seeded_(23)
+    hip = HipEvaViTg(depth=2, device=dev, op_dtype=torch.bfloat16, residual=residual).eval()
+    hip.load_state_dict(ref.state_dict())
+    frames = make_frames(3, seed=24)
+    with torch.no_grad():
+        want = ref(frames)
+    y = hip(frames.to(dev)).float().cpu()
+    hip.set_option("ln_fold", 0)
+    y0 = hip(frames.to(dev)).float().cpu()
+    rel, rel0, both = [((a - b).norm() / want.norm()).item() for a, b in ((y, want), (y0, want), (y, y0))]
+    print(f"vit bf16 depth 2 residual {residual}: rel error folded {rel:.3e}, separate {rel0:.3e}, one against the other {both:.3e}")
+    assert torch.isfinite(y).all() and torch.isfinite(y0).all()
+    bar = 1.2e-2 if residual == "fp32" else 2.5e-2
+    assert rel < bar and rel0 < bar and both < bar, (rel, rel0, both)
+
+
 def test_hip_vit_ragged_batches_and_errors(pair, dev):
     from mraudio_amd import MraError
 
