@@ -53,12 +53,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(MRA_GLB_PTR(gsrc), MRA_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
-// 4-byte async copy global -> LDS (destination: wave-uniform base + lane * 4): used as an L2 "touch" -- the line of `gsrc` is pulled into
-// the XCD's L2 without a register destination that the compiler could reuse while the load is in flight
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(MRA_GLB_PTR(gsrc), MRA_LDS_PTR(lds_wave_base), 4, 0, 0);
-}
-
 // same with the non-temporal cache policy (aux = 2): for bytes ONE workgroup reads once (MI355X_MICROARCH.md, nt-weights)
 __device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(MRA_GLB_PTR(gsrc), MRA_LDS_PTR(lds_wave_base), 16, 0, 2);
