@@ -448,8 +448,65 @@ static void vit_epi_ab(int rounds) {
   }
 }
 
+// the eight-phase 256 x 256 kernel (8 waves of 128 x 64) against experiment 10 (4 waves of 128 x 128) on the ViT's fc1 / QKV shapes, random
+// operands (the clock the chip holds depends on the data), at the 256- and the 1024-frame batch; outputs compared element by element
+static void w4_ab(int rounds) {
+  const int K = 1408;
+  std::mt19937 rng(11);
+  std::normal_distribution<float> d(0.f, 1.f);
+  const size_t Mmax = 263168, Nmax = 6144;
+  std::vector<_Float16> ha(Mmax * K), hw(Nmax * K);
+  for (auto& v : ha) v = (_Float16)d(rng);
+  for (auto& v : hw) v = (_Float16)(0.05f * d(rng));
+  _Float16 *A, *W, *C0, *C1;
+  float* bias;
+  CK(hipMalloc((void**)&A, ha.size() * 2)); CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&W, hw.size() * 2)); CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C0, Mmax * Nmax * 2)); CK(hipMalloc((void**)&C1, Mmax * Nmax * 2));
+  CK(hipMalloc((void**)&bias, Nmax * 4)); CK(hipMemset(bias, 0, Nmax * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int M : {65792, 263168})
+    for (int N : {6144, 4608})
+      for (int epi : {EPI_OP, EPI_GELU_OP}) {
+        if (epi == EPI_GELU_OP && N != 6144) continue;
+        double t[3] = {0, 0, 0};
+        const int variants[3] = {5, 10, 11};
+        for (int v = 0; v < 3; ++v) {
+          gemm_force_variant(variants[v]);
+          GemmProb p{};
+          p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.C = v ? C1 : C0; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.tile_cfg = 3;
+          double best = 1e30;
+          for (int r = 0; r < rounds; ++r) {
+            if (launch_gemm(&p, 1, epi, OP_F16, 0)) { printf("variant %d refused\n", variants[v]); best = -1; break; }
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 3; ++i) launch_gemm(&p, 1, epi, OP_F16, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, (double)ms / 3 * 1e3);
+          }
+          t[v] = best;
+        }
+        gemm_force_variant(5);
+        // compare a sample of rows (the first 512 and the last 300)
+        double worst = 0;
+        for (int part = 0; part < 2; ++part) {
+          const size_t r0 = part ? (size_t)M - 300 : 0, nr = part ? 300 : 512;
+          std::vector<_Float16> c0(nr * N), c1(nr * N);
+          CK(hipMemcpy(c0.data(), C0 + r0 * N, nr * N * 2, hipMemcpyDeviceToHost));
+          CK(hipMemcpy(c1.data(), C1 + r0 * N, nr * N * 2, hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < c0.size(); ++i) worst = std::max(worst, (double)fabsf((float)c0[i] - (float)c1[i]));
+        }
+        printf("M %6d N %4d epi %d: eight-phase %8.1f us %7.1f TF/s | w4 %8.1f us %7.1f TF/s | w4p %8.1f us %7.1f TF/s | max |d| (w4p vs eight-phase) %.3e\n", M, N, epi, t[0],
+               2.0 * M * N * K / t[0] * 1e-6, t[1], 2.0 * M * N * K / t[1] * 1e-6, t[2], 2.0 * M * N * K / t[2] * 1e-6, worst);
+      }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "w4")) { w4_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "vitepi")) { vit_epi_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "race")) { race_screen(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "chain")) { chain_ab(rounds); return 0; }
