@@ -451,11 +451,10 @@ static void vit_epi_ab(int rounds) {
 // the eight-phase 256 x 256 kernel (8 waves of 128 x 64) against experiment 10 (4 waves of 128 x 128) on the ViT's fc1 / QKV shapes, random
 // operands (the clock the chip holds depends on the data), at the 256- and the 1024-frame batch; outputs compared element by element
 static void w4_ab(int rounds) {
-  const int K = 1408;
   std::mt19937 rng(11);
   std::normal_distribution<float> d(0.f, 1.f);
   const size_t Mmax = 263168, Nmax = 6144;
-  std::vector<_Float16> ha(Mmax * K), hw(Nmax * K);
+  std::vector<_Float16> ha(Mmax * 1408), hw(Nmax * 2816);
   for (auto& v : ha) v = (_Float16)d(rng);
   for (auto& v : hw) v = (_Float16)(0.05f * d(rng));
   _Float16 *A, *W, *C0, *C1;
@@ -466,10 +465,12 @@ static void w4_ab(int rounds) {
   CK(hipMalloc((void**)&bias, Nmax * 4)); CK(hipMemset(bias, 0, Nmax * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int K : {1408, 2816})                  // the second K separates the cost per K tile from the fixed cost per output tile
   for (int M : {65792, 263168})
     for (int N : {6144, 4608})
       for (int epi : {EPI_OP, EPI_GELU_OP}) {
         if (epi == EPI_GELU_OP && N != 6144) continue;
+        if (K != 1408 && (M != 65792 || N != 6144 || epi != EPI_OP)) continue;
         double t[3] = {0, 0, 0};
         const int variants[3] = {5, 10, 11};
         for (int v = 0; v < 3; ++v) {
@@ -499,7 +500,7 @@ static void w4_ab(int rounds) {
           CK(hipMemcpy(c1.data(), C1 + r0 * N, nr * N * 2, hipMemcpyDeviceToHost));
           for (size_t i = 0; i < c0.size(); ++i) worst = std::max(worst, (double)fabsf((float)c0[i] - (float)c1[i]));
         }
-        printf("M %6d N %4d epi %d: eight-phase %8.1f us %7.1f TF/s | w4 %8.1f us %7.1f TF/s | w4p %8.1f us %7.1f TF/s | max |d| (w4p vs eight-phase) %.3e\n", M, N, epi, t[0],
+        printf("K %4d M %6d N %4d epi %d: eight-phase %8.1f us %7.1f TF/s | w4 %8.1f us %7.1f TF/s | w4p %8.1f us %7.1f TF/s | max |d| (w4p vs eight-phase) %.3e\n", K, M, N, epi, t[0],
                2.0 * M * N * K / t[0] * 1e-6, t[1], 2.0 * M * N * K / t[1] * 1e-6, t[2], 2.0 * M * N * K / t[2] * 1e-6, worst);
       }
 }
