@@ -294,6 +294,8 @@ double mra_vit_flops(mra_vit* h, int32_t frames);
  * LayerNorm also writes the rows' operand-dtype copy and 128-column statistics (with the residual stream in the operand dtype the stream is
  * that copy and only 64-column statistics are added), the QKV / fc1 GEMM finishes the LayerNorm in its epilogue; the rows are not read back and
  * no LayerNorm kernel runs.  0: separate LayerNorm launches (round 2's form), for A/B and parity runs.
+ * "gemm_persist" (default 1): the QKV / fc1 GEMMs as ONE persistent workgroup per CU walking over the output tiles in the launch's tile order
+ * instead of one workgroup per tile (no workgroup turnaround, arguments fetched once; bit-identical results; 0 = off, 2 = only up to 64 rounds).
  * "attn_persist" (default 0; 257-token frames): 1 = the attention core as one persistent workgroup per CU that fetches the K / V rows of its
  * next (frame, head) unit into registers while it works on the current one (bit-identical results; measured slower). */
 int mra_vit_set_option(mra_vit* h, const char* name, int32_t value);

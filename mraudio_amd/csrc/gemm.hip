@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(768) gemm_ws_kernel(const GemmArgs args) {
 // instruction per wave) and X0 / X1 32 KB (four): 80 KB per K tile, all 160 KB of LDS, vmcnt(9) = 4 + 1 + 4 for the three youngest
 // half-tiles.  Reads, MFMAs and barriers are unchanged.
 template <typename T, int EPI, bool TAIL>
-__device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) {
+__device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0, unsigned long long* dbg = nullptr) {
   constexpr int TN = TAIL ? 128 : 256, TM = TAIL ? 512 : 256, BK = 64, ROWB = BK * 2, WTN = 128, WTM = 64, FN = 8, FM = 4;
   constexpr int WHALF = (TAIL ? 64 : 128) * ROWB, XHALF = (TAIL ? 256 : 128) * ROWB;   // half-tile sizes: W0, W1 | X0, X1
   constexpr int BUF = 2 * WHALF + 2 * XHALF;                                           // 64 KB (80 KB) per K tile
@@ -887,6 +887,14 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   const int K = P.K, M = P.M;
   const int nk = K / BK;
 
+#ifdef MRA_GEMM_EXPERIMENTS
+  // stamped timeline (gemm_bench p8stamp): per workgroup and wave 8 x u64 of wall clock (100 MHz) at the phase boundaries
+  unsigned long long* stamp = dbg ? dbg + ((size_t)blockIdx.x * 8 + wave) * 8 : nullptr;
+#define P8_STAMP(i) do { if (stamp && lane == 0) stamp[i] = wall_clock64(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
+  P8_STAMP(0);
   // DMA sources: piece c of a half-tile is this lane's chunk q = tid + 512 c: LDS row q >> 3, physical chunk q & 7
   const char* srcw[2][WP];
   const char* srcx[2][XP];
@@ -974,12 +982,16 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   // prologue: all of tile 0 (E) and X0 / W0 / X1 of tile 1 (O); W1(O) follows in phase 1
   stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
   stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
+  P8_STAMP(1);   // addresses computed, prologue DMA issued
   if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   P8_BAR();
   if (wr == 1) P8_BAR();   // the stagger
+  P8_STAMP(2);   // first K tile landed
 
   const int npair = nk >> 1;
   for (int it = 0; it < npair; ++it) {
+    if (it == 1) P8_STAMP(3);   // one pair of K tiles done
+    if (it == npair - 1) P8_STAMP(4);   // before the last pair
     const int kt = 2 * it;
     const bool more = it + 1 < npair;        // another pair follows: its half-tiles are staged in phases 2-8
     char* E = smem;
@@ -1051,6 +1063,7 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
     mma(4, 0, x0);
     P8_BAR();
   }
+  P8_STAMP(5);   // K loop done
   if (wr == 0) P8_BAR();   // re-join the two wave groups
 #undef P8_BAR
   const int wn0 = TAIL ? 0 : wr * WTN, wm0 = (TAIL ? wave : wc) * WTM;
@@ -1069,13 +1082,34 @@ __device__ __forceinline__ void gemm_p8_tile(const GemmProb& P, int n0, int m0) 
   } else {
     epilogue<T, FN, FM, EPI, EPI == EPI_RES_F32>(P, acc, n0 + wn0, m0 + wm0, lane);
   }
+  P8_STAMP(6);   // epilogue issued
+#undef P8_STAMP
 }
 
 template <typename T, int EPI, bool TAIL = false>
 __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
   int n0, m0;
+#ifdef MRA_GEMM_EXPERIMENTS
+  if (args.dbg && threadIdx.x == 0) args.dbg[((size_t)blockIdx.x * 8) * 8 + 7] = wall_clock64();   // kernel entry, before the tile lookup
+#endif
   const GemmProb P = pick_tile<(TAIL ? 128 : 256), (TAIL ? 512 : 256)>(args, n0, m0);
-  gemm_p8_tile<T, EPI, TAIL>(P, n0, m0);
+  gemm_p8_tile<T, EPI, TAIL>(P, n0, m0, args.dbg);
+}
+
+// GemmProb::persist: the same tiles in the same order (the XCD remap sees the virtual block index), one workgroup per CU.  Between two tiles
+// one barrier: the staged epilogue's LDS image has been read (its global stores may still be in flight) before the next tile's DMA lands in it.
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) gemm_p8_persist_kernel(const GemmArgs args) {
+  const int nwg = args.total_tiles;
+  const int q = nwg >> 3, r = nwg & 7;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int xcd = vb & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    int n0, m0;
+    const GemmProb P = tile_of<256, 256>(args, id, n0, m0);
+    gemm_p8_tile<T, EPI, false>(P, n0, m0);
+    __syncthreads();
+  }
 }
 
 // N = 256 k + 128 (the ViT's N = 1408) without a masked half tile AND without a second pass over the activations: one launch, eleven
@@ -1083,8 +1117,8 @@ __global__ void __launch_bounds__(512) gemm_p8_kernel(const GemmArgs args) {
 // that order after the XCD remap, so the tiles that share activation rows run together and share them in L2.  (As its own launch
 // the tail re-streams every activation row from HBM: measured slower than the masked tile.)  One problem, no batch.
 template <typename T, int EPI>
-__global__ void __launch_bounds__(512) gemm_p8_mixed_kernel(const GemmArgs args) {
-  int id = blockIdx.x;
+__device__ __forceinline__ void gemm_p8_mixed_tile(const GemmArgs& args, int vb) {
+  int id = vb;
   {
     const int nwg = args.total_tiles;
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -1100,6 +1134,10 @@ __global__ void __launch_bounds__(512) gemm_p8_mixed_kernel(const GemmArgs args)
     if (rt * 256 >= P.M) return;                         // odd number of row tiles: the last pair has one
     gemm_p8_tile<T, EPI, false>(P, (w % kfull) * 256, rt * 256);
   }
+}
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) gemm_p8_mixed_kernel(const GemmArgs args) {
+  gemm_p8_mixed_tile<T, EPI>(args, blockIdx.x);
 }
 
 // =================================================================================================
@@ -1584,6 +1622,25 @@ int launch_p8(const GemmArgs& a, int epi, hipStream_t stream, bool tail = false)
       case EPI_RES_F32_STAT: return launch_k(gemm_p8_kernel<T, EPI_RES_F32_STAT, true>, a, 512, ldst, stream);
       case EPI_F32: return launch_k(gemm_p8_kernel<T, EPI_F32, true>, a, 512, ldst, stream);
       default: return -2;
+    }
+  }
+  if (a.p[0].persist && a.ngroups == 1 && a.p[0].batch <= 1) {   // one workgroup per CU (the grid must be a multiple of the 8 XCDs for the remap to hold)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8 && a.total_tiles > cus) {
+      const int grid = cus & ~7;
+      auto go = [&](auto kfn) {
+        if (!ensure_lds((const void*)kfn, lds)) return -3;
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, stream, a);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+      };
+      switch (epi) {
+        case EPI_OP: return go(gemm_p8_persist_kernel<T, EPI_OP>);
+        case EPI_GELU_OP: return go(gemm_p8_persist_kernel<T, EPI_GELU_OP>);
+        case EPI_LNF_OP: return go(gemm_p8_persist_kernel<T, EPI_LNF_OP>);
+        case EPI_LNF_GELU_OP: return go(gemm_p8_persist_kernel<T, EPI_LNF_GELU_OP>);
+        case EPI_KV: return go(gemm_p8_persist_kernel<T, EPI_KV>);
+        default: break;   // the direct epilogues: one workgroup per tile
+      }
     }
   }
   switch (epi) {

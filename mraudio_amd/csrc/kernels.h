@@ -109,6 +109,9 @@ struct GemmProb {
                    // workgroup per CU at 2048 x 2304, 2 x 1024 x 3072 and 2048 x 768 (plain problems, N a multiple of the tile, EPI_OP / GELU_OP / RES_F32 / F32)
   int order;       // tile walk: 0 = panels of 8 row tiles, rows fastest; gn > 0 = panels of gn column tiles walked down the rows, columns
                    // fastest (measured better for the ViT's N = 1408 GEMMs: all 6 column tiles of a row tile run together)
+  int persist;     // eight-phase 256 x 256 kernel, staged epilogues: 1 = ONE workgroup per CU walks over the tiles (blockIdx, + gridDim, ...) instead of one
+                   // workgroup per tile.  A stamped timeline (gemm_bench p8stamp, fc1 shape) shows ~3.8 us between the end of a workgroup and the start
+                   // of the next on its CU plus ~1.8 us of kernel entry / argument fetch / address set-up per workgroup, of a ~50 us tile
   int tile_begin;  // filled by the launcher
   int mtiles, ntiles;
   int batch_row0;  // filled per workgroup: first row of its batch entry in the EPI_SOFTPART statistics

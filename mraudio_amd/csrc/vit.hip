@@ -564,6 +564,10 @@ struct mra_vit {
                        // 176 x 384 tile (tile_cfg 5) measured 1 % slower (615 vs 609 ms per 1024 frames): both sit on the fp32 epilogue
   // LayerNorms folded into the QKV / fc1 GEMMs (dim = 256 k + 128): mra_vit_set_option("ln_fold", 0 / 1)
   int ln_fold = 1;
+  int gemm_persist = 1;   // QKV / fc1 on the eight-phase kernel as one persistent workgroup per CU (GemmProb::persist): 0 never, 1 always, 2 up to 64 rounds of
+                          // the chip.  Measured in the encoder (r03final, alternating in one process, bit-identical outputs): 20.1 -> 19.9 ms at 32 frames,
+                          // 139.8 -> 138.4 at 256, 547.4 -> 538.7 at 1024.  (The projection / fc2 GEMMs on the mixed-tile kernel lose with the same treatment:
+                          // 549.4 against 538.9 ms -- their two tile kinds and the residual read at the head of a tile want the dispatcher's dynamic order; not built in.)
   int attn_persist = 0;   // S = 257: the attention core as one persistent workgroup per CU that prefetches the next (frame, head) unit (vit_attn_persist_kernel).
                           // Measured SLOWER (r03z: 303 vs 277 us per launch at 256 frames, 576-579 vs 573-576 ms per 1024 frames): its register budget allows
                           // eight waves, and 17 query blocks over eight waves put three blocks in series on one wave; opt-in
@@ -723,6 +727,11 @@ int mra_vit_set_option(mra_vit* h, const char* name, int32_t value) {
     h->ln_fold = value;
     return MRA_OK;
   }
+  if (key == "gemm_persist") {
+    if (value < 0 || value > 2) return fail(MRA_EINVAL, "gemm_persist: 0, 1 or 2 (automatic)");
+    h->gemm_persist = value;
+    return MRA_OK;
+  }
   if (key == "attn_persist") {
     if (value != 0 && value != 1) return fail(MRA_EINVAL, "attn_persist: 0 or 1");
     h->attn_persist = value;
@@ -833,6 +842,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       else hipLaunchKernelGGL(vit_row_stats_kernel<bf16>, grid, block, 0, st, out, M, D, c.ln_eps, rstat, (bf16*)x16);
     }
   }
+  auto persist = [&](long long tiles) { return h->gemm_persist == 1 || (h->gemm_persist == 2 && h->cus > 0 && tiles <= 64LL * h->cus) ? 1 : 0; };
   auto row_stats = [&]() {
     hipLaunchKernelGGL(vit_group_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, groups, M, D / gsz, (float)gsz, c.ln_eps, rstat);
   };
@@ -847,6 +857,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       p.A = fold ? x16 : a16; p.a = plain((int)M, D); p.W = fold ? L.wqkv_f : L.wqkv; p.bias = fold ? L.bf_qkv : L.bqkv;
       p.C = big; p.c = plain((int)M, h->nqkv); p.M = (int)M; p.N = h->nqkv; p.K = D;
       if (fold) { p.ln_gain = L.cs_qkv; p.ln_y32 = reinterpret_cast<float*>(rstat); p.tile_cfg = 3; }
+      p.persist = persist((M + 255) / 256 * (h->nqkv / 256));
       rc = launch_gemm(&p, 1, fold ? EPI_LNF_OP : EPI_OP, op, st);
       if (rc) return chk(rc, "vit qkv gemm");
     }
@@ -891,6 +902,7 @@ int mra_vit_forward(mra_vit* h, const void* frames, int32_t dtype, int32_t n, vo
       p.A = fold ? x16 : a16; p.a = plain((int)M, D); p.W = fold ? L.wfc1_f : L.wfc1; p.bias = fold ? L.bf_fc1 : L.bfc1;
       p.C = big; p.c = plain((int)M, I); p.M = (int)M; p.N = I; p.K = D;
       if (fold) { p.ln_gain = L.cs_fc1; p.ln_y32 = reinterpret_cast<float*>(rstat); p.tile_cfg = 3; }
+      p.persist = persist((M + 255) / 256 * (I / 256));
       rc = launch_gemm(&p, 1, fold ? EPI_LNF_GELU_OP : EPI_GELU_OP, op, st);
       if (rc) return chk(rc, "vit fc1 gemm");
     }

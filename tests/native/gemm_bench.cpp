@@ -472,11 +472,12 @@ static void w4_ab(int rounds) {
         if (epi == EPI_GELU_OP && N != 6144) continue;
         if (K != 1408 && (M != 65792 || N != 6144 || epi != EPI_OP)) continue;
         double t[3] = {0, 0, 0};
-        const int variants[3] = {5, 10, 11};
+        const int variants[3] = {5, 5, 11};          // the middle one: the eight-phase kernel as a persistent workgroup per CU (GemmProb::persist)
         for (int v = 0; v < 3; ++v) {
           gemm_force_variant(variants[v]);
           GemmProb p{};
-          p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.C = v ? C1 : C0; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.tile_cfg = 3;
+          p.persist = v == 1;
+          p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.C = v == 1 ? C1 : C0; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.tile_cfg = 3;
           double best = 1e30;
           for (int r = 0; r < rounds; ++r) {
             if (launch_gemm(&p, 1, epi, OP_F16, 0)) { printf("variant %d refused\n", variants[v]); best = -1; break; }
@@ -500,13 +501,62 @@ static void w4_ab(int rounds) {
           CK(hipMemcpy(c1.data(), C1 + r0 * N, nr * N * 2, hipMemcpyDeviceToHost));
           for (size_t i = 0; i < c0.size(); ++i) worst = std::max(worst, (double)fabsf((float)c0[i] - (float)c1[i]));
         }
-        printf("K %4d M %6d N %4d epi %d: eight-phase %8.1f us %7.1f TF/s | w4 %8.1f us %7.1f TF/s | w4p %8.1f us %7.1f TF/s | max |d| (w4p vs eight-phase) %.3e\n", K, M, N, epi, t[0],
+        printf("K %4d M %6d N %4d epi %d: eight-phase %8.1f us %7.1f TF/s | persistent %8.1f us %7.1f TF/s | w4p %8.1f us %7.1f TF/s | max |d| (persistent vs the others) %.3e\n", K, M, N, epi, t[0],
                2.0 * M * N * K / t[0] * 1e-6, t[1], 2.0 * M * N * K / t[1] * 1e-6, t[2], 2.0 * M * N * K / t[2] * 1e-6, worst);
       }
 }
 
+// stamped timeline of the eight-phase kernel on the ViT's fc1 shape (256 frames): where the ~14 us of fixed cost per output tile go
+static void p8_stamp() {
+  const int M = 65792, N = 6144, K = 1408;
+  std::mt19937 rng(5);
+  std::normal_distribution<float> d(0.f, 1.f);
+  std::vector<_Float16> ha((size_t)M * K), hw((size_t)N * K);
+  for (auto& v : ha) v = (_Float16)d(rng);
+  for (auto& v : hw) v = (_Float16)(0.05f * d(rng));
+  _Float16 *A, *W, *C;
+  float* bias;
+  CK(hipMalloc((void**)&A, ha.size() * 2)); CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&W, hw.size() * 2)); CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&C, (size_t)M * N * 2)); CK(hipMalloc((void**)&bias, N * 4)); CK(hipMemset(bias, 0, N * 4));
+  const int tiles = 257 * 24;
+  unsigned long long* dbg;
+  const size_t nent = (size_t)tiles * 8 * 8;
+  CK(hipMalloc((void**)&dbg, nent * 8));
+  GemmProb p{};
+  p.A = A; p.a = RowView{0, M, K}; p.W = W; p.bias = bias; p.C = C; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.tile_cfg = 3;
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, EPI_OP, OP_F16, 0);
+    CK(hipMemset(dbg, 0, nent * 8));
+    gemm_set_debug_buffer(dbg);
+    launch_gemm(&p, 1, EPI_OP, OP_F16, 0);
+    CK(hipDeviceSynchronize());
+    gemm_set_debug_buffer(nullptr);
+    std::vector<unsigned long long> s(nent);
+    CK(hipMemcpy(s.data(), dbg, nent * 8, hipMemcpyDeviceToHost));
+    const char* names[7] = {"tile function entered", "addresses + prologue DMA issued", "first K tile landed, barrier passed", "first pair of K tiles done", "last pair begins",
+                            "K loop done", "epilogue issued (kernel end)"};
+    // intervals of wave 0 and wave 4 of every workgroup, averaged; the time from kernel entry (thread 0) to the tile function as well
+    for (int w : {0, 4}) {
+      double sum[7] = {0}, entry = 0;
+      for (int b = 0; b < tiles; ++b) {
+        const unsigned long long* q = &s[((size_t)b * 8 + w) * 8];
+        for (int e = 0; e < 7; ++e) sum[e] += (double)(q[e] - q[0]) * 0.01;
+        entry += (double)(q[0] - s[((size_t)b * 8) * 8 + 7]) * 0.01;
+      }
+      printf("wave %d: kernel entry -> tile function %.2f us; then (us after the tile function's start, mean over %d workgroups):\n", w, entry / tiles, tiles);
+      for (int e = 0; e < 7; ++e) printf("  %-40s %7.2f\n", names[e], sum[e] / tiles);
+    }
+    // workgroup turnaround on a CU: end of one workgroup -> start of the next cannot be read from here; the launch's span / rounds is printed instead
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = 0; b < tiles; ++b) { t0 = std::min(t0, s[((size_t)b * 8) * 8 + 7]); t1 = std::max(t1, s[((size_t)b * 8) * 8 + 6]); }
+    printf("launch span %.1f us = %.2f us per round of 256 tiles (%.2f rounds)\n", (double)(t1 - t0) * 0.01, (double)(t1 - t0) * 0.01 / (tiles / 256.0), tiles / 256.0);
+  }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "p8stamp")) { p8_stamp(); return 0; }
   if (argc > 2 && !strcmp(argv[2], "w4")) { w4_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "vitepi")) { vit_epi_ab(rounds); return 0; }
   if (argc > 2 && !strcmp(argv[2], "race")) { race_screen(rounds); return 0; }

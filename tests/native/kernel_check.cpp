@@ -87,6 +87,7 @@ static long long voff(const RowView& v, int m) { return (long long)(m / v.rpi) *
 
 // ------------------------------------------------------------------------------------------------
 static int g_test_order = 0;   // GemmProb::order of the next test_gemm problems (tile walk)
+static int g_test_persist = 0; // GemmProb::persist of the next test_gemm problems (one workgroup per CU)
 static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views, int groups = 1) {
   // activations live in [items, S, K] with the rows of interest at [:, off:off+rpi]
   const int rpi = views ? 5 : (M > 0 ? M : 1);
@@ -143,7 +144,7 @@ static void test_gemm(int cfg, int epi, int op, int M, int N, int K, bool views,
     p.N = N;
     p.K = K;
     p.tile_cfg = cfg >= 0 ? cfg + 1 : 0;   // per problem: the shipped library has no global switches
-    p.order = g_test_order;
+    p.order = g_test_order; p.persist = g_test_persist;
     if (epi == EPI_RES_F32 || epi == EPI_F32) {
       p.C = dC32[q]->p + (size_t)off * ldc;
       p.c = x.cv;
@@ -563,7 +564,7 @@ static void test_gemm_masked(int cfg, int epi, int op, int M, int N, int K) {
   GemmProb p;
   memset(&p, 0, sizeof(p));
   p.A = dA.p; p.a = RowView{0, M, K}; p.W = dW.p; p.bias = dB.p; p.R = dR.p; p.r = RowView{0, M, N};
-  p.C = dC.p; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.n_mask = 1; p.tile_cfg = cfg + 1; p.order = g_test_order;
+  p.C = dC.p; p.c = RowView{0, M, N}; p.M = M; p.N = N; p.K = K; p.n_mask = 1; p.tile_cfg = cfg + 1; p.order = g_test_order; p.persist = g_test_persist;
   const int rc = launch_gemm(&p, 1, epi, op, 0);
   CK(hipDeviceSynchronize());
   std::vector<float> c = dC.get();
@@ -1312,6 +1313,11 @@ int main(int argc, char** argv) {
   test_gemm(6, EPI_F32, OP_BF16, 1000, 128, 128, false);
   test_gemm(6, EPI_RES_OP, OP_F16, 700, 128, 1408, true);
   test_gemm(6, EPI_RES_F32, OP_F16, 512, 128, 6144, false);
+  g_test_persist = 1;                                              // the eight-phase kernel as one persistent workgroup per CU: more tiles than CUs, ragged M, views
+  test_gemm(2, EPI_OP, OP_F16, 17 * 256 - 90, 4096, 256, true);
+  test_gemm(2, EPI_GELU_OP, OP_BF16, 4200, 4096, 128, false);
+  test_gemm(2, EPI_KV, OP_F16, 9 * 256 + 10, 8192, 128, false);
+  g_test_persist = 0;
   test_gemm_ln_fold(OP_F16, 700, 384, 256, 512, false, 0.f);      // LayerNorm folded into the producer / consumer GEMMs: mixed tiles (N = 256 k + 128), ragged M
   test_gemm_ln_fold(OP_F16, 1300, 1408, 128, 256, true, 0.f);      // the ViT's width: 11 groups, odd number of row tiles, GELU consumer
   test_gemm_ln_fold(OP_F16, 520, 640, 384, 256, false, 8.f);       // row means 8 sigma from zero

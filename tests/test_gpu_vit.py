@@ -52,6 +52,15 @@ def test_hip_vit_matches_the_hf_vectors_and_the_fp32_restatement(pair, golden_di
     more = torch.cat([make_frames(3, seed=21), frames])
     ym = hip(more.to(dev)).cpu()
     assert (ym[3:] - y).abs().max().item() < 1e-4
+    # QKV / fc1 as one persistent workgroup per CU (default) against one workgroup per tile: the same tiles, bit for bit (32 frames: 594 / 792 tiles)
+    big_batch = make_frames(32, seed=22).to(dev)
+    yb = hip(big_batch).cpu()
+    hip.set_option("gemm_persist", 0)
+    try:
+        yb0 = hip(big_batch).cpu()
+    finally:
+        hip.set_option("gemm_persist", 1)
+    assert torch.equal(yb, yb0)
     # the attention core as persistent workgroups that prefetch the next (frame, head) unit (opt-in: measured slower) against one workgroup
     # per unit -- the same arithmetic in the same order, bit for bit
     hip.set_option("attn_persist", 1)

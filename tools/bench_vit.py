@@ -17,6 +17,7 @@ ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--backend", default="hip")
 ap.add_argument("--residual", default="fp32", choices=["fp32", "op"])
 ap.add_argument("--attn-persist", type=int, default=0, help="1: the attention core as persistent workgroups that prefetch the next unit (mra_vit_set_option attn_persist 1; measured slower)")
+ap.add_argument("--gemm-persist", type=int, nargs="*", default=None, help="A/B: mra_vit_set_option('gemm_persist', v) values timed one after the other in this process")
 ap.add_argument("--ln-fold", type=int, default=1, help="0: the blocks' LayerNorms as separate launches (mra_vit_set_option ln_fold 0)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -28,6 +29,24 @@ else:
 if a.backend == "hip" and a.attn_persist:
     vit.set_option("attn_persist", 1)
 x = torch.randn(a.frames, 3, 224, 224, device=dev, dtype=torch.float16)
+if a.gemm_persist:
+    with torch.no_grad():
+        vit(x)
+        ref = None
+        for rnd in range(2):
+            for v in a.gemm_persist:
+                vit.set_option("gemm_persist", v)
+                vit(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.reps):
+                    y = vit(x)
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t0) / a.reps
+                ref = y.clone() if ref is None else ref
+                print(json.dumps({"gemm_persist": v, "frames": a.frames, "ms": round(t * 1e3, 3), "tflops": round(vit.flops_per_frame() * a.frames / t / 1e12, 1),
+                                  "max_abs_diff_vs_first": float((y - ref).abs().max())}), flush=True)
+    sys.exit(0)
 with torch.no_grad():
     vit(x)
     torch.cuda.synchronize()
