@@ -415,6 +415,7 @@ int kv_project(const mra_qformer* h, const void* enc, int N, int kv, void* kv_ca
   p.kv_tokens = kv;
   p.kv_items = N;
   p.kv_heads = c.heads;
+  p.persist = 1;   // on the eight-phase kernel: one persistent workgroup per CU (bit-identical; no workgroup turnaround between tiles)
   return launch_gemm(&p, 1, EPI_KV, h->op(), stream);
 }
 
